@@ -1,0 +1,189 @@
+/*
+ * orbx.h — C ABI of the MI355X (gfx950) ORB front end.
+ *
+ * Drop-in boundary for two pieces of One-sixth/my_orb_slam2 (paths below are relative to
+ * my_orb_slam2/ in that repository):
+ *   - ORBextractor::operator()(image, mask, keypoints, descriptors)   include/ORBextractor.h:66-68
+ *   - ORBmatcher::DescriptorDistance + the brute-force best/second-best scans that call it
+ *                                                                      include/ORBmatcher.h:47
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary; nothing throws.
+ * Every function returns ORBX_OK (0) or a negative ORBX_ERR_* code; orbx_last_error() gives the
+ * text of the calling thread's last failure.
+ *
+ * Threading: one orbx_ctx owns one HIP stream and its device buffers. Different contexts may be
+ * used from different threads at the same time (the reference runs its left and right extractor
+ * on two threads, src/Frame.cc:97-110); a single context is not re-entrant, exactly like an
+ * ORBextractor instance (its mvImagePyramid member is per-call state, include/ORBextractor.h:100).
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_OK 0
+#define ORBX_ERR_INVALID (-1)   /* bad argument */
+#define ORBX_ERR_HIP (-2)       /* a HIP runtime call failed (no GPU, out of memory, ...) */
+#define ORBX_ERR_CAPACITY (-3)  /* output capacity too small; *n holds the required count */
+#define ORBX_ERR_STATE (-4)     /* call order: nothing extracted yet, frame index out of range */
+
+#define ORBX_MAX_LEVELS 16
+#define ORBX_DESC_BYTES 32
+
+/* Gaussian tap sets of cv::GaussianBlur(7x7, sigma 2) in 8.8 fixed point (src/ORBextractor.cc:1078).
+ * OpenCV 4.0.0 (the version the reference pins) rounds each tap on its own: 18 34 49 55 49 34 18.
+ * OpenCV >= 4.2 forces the sum to 256: 18 34 48 56 48 34 18. */
+#define ORBX_BLUR_CV_4_0_0 0
+#define ORBX_BLUR_CV_4_2_PLUS 1
+
+/* Bit-compatible with cv::KeyPoint (28 bytes), so the reference's map file keypoint block
+ * (src/KeyFrame.cc:934-942) keeps its layout. */
+typedef struct orbx_keypoint {
+    float x, y;       /* pt, in level-0 pixel units (level coords * scale, src/ORBextractor.cc:1092) */
+    float size;       /* (int)(31 * scale[octave])                      (:829, :838) */
+    float angle;      /* intensity-centroid angle in degrees, [0, 360)  (:69-96)    */
+    float response;   /* FAST corner score                                           */
+    int32_t octave;   /* pyramid level                                  (:837)       */
+    int32_t class_id; /* always -1                                                   */
+} orbx_keypoint;
+
+/* Constructor arguments of ORBextractor (include/ORBextractor.h:52-53, src/ORBextractor.cc:402-406)
+ * plus what a device context needs to size its buffers. */
+typedef struct orbx_config {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t device;     /* HIP device ordinal */
+    int32_t max_width;  /* largest image accepted (<= 4096) */
+    int32_t max_height;
+    int32_t max_batch;  /* frames per batched call */
+    int32_t blur_taps;  /* ORBX_BLUR_* */
+} orbx_config;
+
+typedef struct orbx_ctx orbx_ctx;
+
+const char* orbx_last_error(void);
+
+/* ---- extractor --------------------------------------------------------------------------- */
+
+/* Replaces `new ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)`
+ * (src/Tracking.cc:116-122). Fails with ORBX_ERR_HIP when the device is not usable. */
+int orbx_create(const orbx_config* cfg, orbx_ctx** out);
+void orbx_destroy(orbx_ctx* ctx);
+
+/* Getters of include/ORBextractor.h:70-98 (read by every Frame constructor, src/Frame.cc:86-92).
+ * Arrays receive nlevels floats / ints. Host-side only. */
+int orbx_get_levels(const orbx_ctx* ctx);
+float orbx_get_scale_factor(const orbx_ctx* ctx);
+int orbx_get_scale_factors(const orbx_ctx* ctx, float* out);
+int orbx_get_inverse_scale_factors(const orbx_ctx* ctx, float* out);
+int orbx_get_scale_sigma_squares(const orbx_ctx* ctx, float* out);
+int orbx_get_inverse_scale_sigma_squares(const orbx_ctx* ctx, float* out);
+int orbx_get_features_per_level(const orbx_ctx* ctx, int32_t* out); /* mnFeaturesPerLevel (:427-438) */
+int orbx_get_umax(const orbx_ctx* ctx, int32_t* out16);              /* umax (:446-461) */
+/* Capacity that can never overflow: sum over levels of (quota + 3); each level yields at most
+ * quota + 3 keypoints (src/ORBextractor.cc:661-723). */
+int orbx_keypoint_capacity(const orbx_ctx* ctx);
+
+/* ORBextractor::operator() (src/ORBextractor.cc:1035-1097) on one host image (CV_8UC1 rows of
+ * `stride` bytes). The mask argument of the reference is ignored there (include/ORBextractor.h:65)
+ * and has no counterpart here. Writes up to `cap` keypoints and cap*32 descriptor bytes to
+ * caller-owned host buffers and the number found to *n. An empty image (NULL or w/h <= 0) returns
+ * ORBX_OK and leaves every output untouched (:1038-1039). Blocks until the result is on the host. */
+int orbx_extract(orbx_ctx* ctx, const uint8_t* image, int width, int height, size_t stride,
+                 orbx_keypoint* keypoints, uint8_t* descriptors, int cap, int* n);
+
+/* The same on `nframes` (<= max_batch) equally sized frames that already live in device memory;
+ * frame f starts at d_images + f*frame_stride. Outputs are device buffers: d_keypoints[f*cap ..],
+ * d_descriptors[(f*cap ..)*32], d_counts[f] = keypoints found in frame f (only the first `cap` are
+ * stored). Work is enqueued on `stream` (a hipStream_t; NULL = the context's own stream) and the
+ * call returns without waiting. */
+int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_images, int nframes, int width,
+                              int height, size_t row_stride, size_t frame_stride,
+                              orbx_keypoint* d_keypoints, uint8_t* d_descriptors, int cap,
+                              int32_t* d_counts, void* stream);
+/* Host-buffer form of the batched call (H2D, extract, D2H; blocks). */
+int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* images, int nframes, int width, int height,
+                       size_t row_stride, size_t frame_stride, orbx_keypoint* keypoints,
+                       uint8_t* descriptors, int cap, int32_t* counts);
+int orbx_synchronize(orbx_ctx* ctx);
+
+/* mvImagePyramid[level] of frame `frame` of the last call (include/ORBextractor.h:100; read by
+ * src/Frame.cc:510,600,612,617). With border != 0 the copy is (w+38) x (h+38) and carries the
+ * 19-px BORDER_REFLECT_101 frame of src/ORBextractor.cc:1105-1120. dst is a host buffer. */
+int orbx_level_size(const orbx_ctx* ctx, int level, int* width, int* height);
+int orbx_get_level(orbx_ctx* ctx, int frame, int level, int border, uint8_t* dst, size_t dst_stride);
+
+/* Stage probes of the last call, for parity tests: the blurred level the descriptors sample
+ * (src/ORBextractor.cc:1077-1078), the per-cell FAST candidates in vToDistributeKeys order
+ * (:770-821, coordinates relative to the 16-px border) and the DistributeOctTree selection in
+ * list order (:826-839, level coordinates, response set, angle -1). Host outputs. */
+int orbx_debug_blur_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride);
+int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, orbx_keypoint* out, int cap, int* n);
+int orbx_debug_selected(orbx_ctx* ctx, int frame, int level, orbx_keypoint* out, int cap, int* n);
+
+/* ---- matcher ----------------------------------------------------------------------------- */
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1698-1714) for host callers. */
+int orbx_hamming256(const uint8_t* a, const uint8_t* b);
+
+typedef struct orbx_matcher orbx_matcher;
+int orbx_matcher_create(int device, orbx_matcher** out);
+void orbx_matcher_destroy(orbx_matcher* m);
+
+/* Brute-force best / second-best scan with the update rule of src/ORBmatcher.cc:204-229
+ * (also :440-465, :587-617): every query against every database row in index order,
+ * `dist < best1` shifts best1 into best2, else `dist < best2` replaces best2; best1 = best2 = init
+ * and idx = -1 before the scan (init is 256 at :204-206, INT_MAX at :440-441). idx/d1/d2 receive
+ * nq int32 each. Device pointers; enqueued on `stream` (NULL = the matcher's own). ndb <= 2^31-1.
+ * db_index_base is added to every returned index (for a database shard). */
+int orbx_hamming_knn2_device(orbx_matcher* m, const uint8_t* d_query, int64_t nq,
+                             const uint8_t* d_db, int64_t ndb, int32_t init, int64_t db_index_base,
+                             int64_t* d_idx, int32_t* d_d1, int32_t* d_d2, void* stream);
+/* Host-buffer form (H2D, scan, D2H; blocks). */
+int orbx_hamming_knn2(orbx_matcher* m, const uint8_t* query, int64_t nq, const uint8_t* db,
+                      int64_t ndb, int32_t init, int64_t* idx, int32_t* d1, int32_t* d2);
+/* Merges `nparts` partial results of the same queries taken over consecutive database shards
+ * (part p holds nq entries at offset p*nq) into the result of one scan over the whole database:
+ * best = smallest d1, earliest shard on ties; second = second smallest of all d1 and d2. */
+int orbx_knn2_merge_device(orbx_matcher* m, int nparts, int64_t nq, const int64_t* d_idx,
+                           const int32_t* d_d1, const int32_t* d_d2, int32_t init,
+                           int64_t* d_out_idx, int32_t* d_out_d1, int32_t* d_out_d2, void* stream);
+/* Acceptance test of the callers: d1 <= th (inclusive != 0: src/ORBmatcher.cc:231,467) or d1 < th
+ * (:619), then (float)d1 < ratio*(float)d2 (:233,469,621). accept receives nq bytes (0/1). */
+int orbx_ratio_test_device(orbx_matcher* m, int64_t nq, const int32_t* d_d1, const int32_t* d_d2,
+                           int32_t th, int inclusive, float ratio, uint8_t* d_accept, void* stream);
+
+/* Descriptor half of Frame::ComputeStereoMatches (src/Frame.cc:503-586) for `npairs` stereo pairs:
+ * pair p has nl[p] left and nr[p] right keypoints stored at kl + p*cap etc. For every left
+ * keypoint: the right keypoint with the smallest distance among those in its row band
+ * (|yR - row| within 2*scale[octaveR], :520-530), octave within +-1 (:570) and
+ * uL - bf/b <= uR <= uL (:553-554,575); strict `<` starting from TH_HIGH = 100, lowest right index
+ * wins ties. best_idx = -1 and best_dist = 100 when nothing qualifies. Device pointers. */
+int orbx_stereo_band_match_device(orbx_matcher* m, int npairs, int cap,
+                                  const orbx_keypoint* d_kl, const uint8_t* d_dl, const int32_t* d_nl,
+                                  const orbx_keypoint* d_kr, const uint8_t* d_dr, const int32_t* d_nr,
+                                  const float* scale_factors, int nlevels, float bf, float b,
+                                  int32_t* d_best_idx, int32_t* d_best_dist, void* stream);
+int orbx_matcher_synchronize(orbx_matcher* m);
+
+/* ---- synthetic frames (host) --------------------------------------------------------------- */
+#define ORBX_SYNTH_SCENE 0
+#define ORBX_SYNTH_ZERO 1
+#define ORBX_SYNTH_CONST128 2
+#define ORBX_SYNTH_NOISE 3
+/* Deterministic test frame `index` (no counterpart in the reference, whose examples read EuRoC
+ * PNGs that are not redistributable offline: orb_slam2_mono_example/mono_euroc.cc:86). */
+int orbx_synth_frame(uint64_t index, int width, int height, int kind, int nrect, int ncheck,
+                     int right_view, uint8_t* out, size_t stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -1,0 +1,243 @@
+// Per-cell FAST-9/16 with threshold fallback and non-maximum suppression
+// (ORBextractor::ComputeKeyPointsOctTree, src/ORBextractor.cc:781-821, which calls
+// cv::FAST(cell, iniThFAST, true) and, when that returns nothing, cv::FAST(cell, minThFAST, true)).
+//
+// One 64-lane wave owns one cell of one frame. A cell is an independent sub-image for the
+// reference: FAST scans it 3 px inside its own border and suppression treats everything outside
+// the scanned rectangle as score 0, so no data crosses cells and no score map goes to HBM.
+//
+//   1. the cell's pixels (cell + 6 px) are staged in LDS as coalesced dwords;
+//   2. every scanned pixel runs the cheap antipodal-pair test at the low threshold; survivors are
+//      queued in LDS in row-major order (ballot + prefix count);
+//   3. queued pixels get the exact corner strength S = max over the 16 arcs of 9 of the smallest
+//      |centre - circle| with one sign; a pixel is a corner at threshold t iff S > t and its FAST
+//      score (cv cornerScore) is S - 1;
+//   4. corners above the active threshold that beat their 8 neighbours strictly are written in
+//      row-major order to the cell's slot array; if none survives at iniThFAST the same LDS score
+//      map is re-read at minThFAST.
+#include "orbx_internal.h"
+
+namespace orbx {
+
+namespace {
+
+// floor(i / n) for 0 <= i < 65536/n, n >= 1 (multiply by a rounded-up reciprocal)
+__device__ __forceinline__ int div_small(int i, int recip) { return (int)(((unsigned)i * (unsigned)recip) >> 16); }
+
+// Corner strength of the pixel at p (LDS, row pitch `pitch`): see step 3 above.
+__device__ __forceinline__ int corner_strength(const uint8_t* p, int pitch) {
+    const int v = p[0];
+    int d[16];
+    d[0] = v - p[3 * pitch];
+    d[1] = v - p[3 * pitch + 1];
+    d[2] = v - p[2 * pitch + 2];
+    d[3] = v - p[pitch + 3];
+    d[4] = v - p[3];
+    d[5] = v - p[-pitch + 3];
+    d[6] = v - p[-2 * pitch + 2];
+    d[7] = v - p[-3 * pitch + 1];
+    d[8] = v - p[-3 * pitch];
+    d[9] = v - p[-3 * pitch - 1];
+    d[10] = v - p[-2 * pitch - 2];
+    d[11] = v - p[-pitch - 3];
+    d[12] = v - p[-3];
+    d[13] = v - p[pitch - 3];
+    d[14] = v - p[2 * pitch - 2];
+    d[15] = v - p[3 * pitch - 1];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    }
+    int a = -256, b = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        a = max(a, min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]));  // darker arc of 9 from k
+        b = min(b, max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]));  // brighter arc of 9 from k
+    }
+    return max(a, -b);
+}
+
+}  // namespace
+
+template <bool ALIGNED4>
+__global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom g, int iniTh, int minTh) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x;
+    const int f = blockIdx.y;
+    const int cell = blockIdx.x;
+    int l = 0;
+    while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellBase) l++;
+    const LevelGeom& L = g.lv[l];
+    const int c = cell - L.cellBase;
+    const int ci = c / L.nCols, cj = c - ci * L.nCols;
+
+    int32_t* countOut = fs.cellCount + (long long)f * g.totalCells + cell;
+    uint32_t* slotOut = fs.slots + (long long)f * g.totalSlots + L.slotBase + (long long)c * L.slotCap;
+
+    // cell rectangle in level coordinates (:783-798)
+    const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+    const int iniX = kBorder + cj * L.wCell, iniY = kBorder + ci * L.hCell;
+    const int maxX = min(iniX + L.wCell + 6, maxBX), maxY = min(iniY + L.hCell + 6, maxBY);
+    const int sw = maxX - iniX - 6, sh = maxY - iniY - 6;  // scanned rectangle (3-px FAST margin)
+    if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || sw <= 0 || sh <= 0) {
+        if (lane == 0) *countOut = 0;
+        return;
+    }
+    const int th = maxY - iniY;
+
+    const uint8_t* img;
+    long long rowStride;
+    if (l == 0) {
+        img = fs.img + (long long)f * fs.imgFrameStride;
+        rowStride = fs.imgRowStride;
+    } else {
+        img = fs.pyr + (long long)f * g.pyrBytes + L.offset;
+        rowStride = L.stride;
+    }
+
+    // ---- 1. stage the cell in LDS ----
+    uint8_t* tile = smem;
+    int pitch, xo;
+    if (ALIGNED4) {
+        const int xa = iniX & ~3;
+        const int ndw = (maxX - xa + 3) >> 2;
+        pitch = ndw * 4;
+        xo = iniX - xa;
+        const int total = ndw * th;
+        const int recip = (65536 + ndw - 1) / ndw;
+        uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile);
+        for (int i = lane; i < total; i += 64) {
+            const int y = div_small(i, recip);
+            const int dwi = i - y * ndw;
+            tile32[i] = *reinterpret_cast<const uint32_t*>(img + (long long)(iniY + y) * rowStride + xa + dwi * 4);
+        }
+    } else {
+        const int tw = maxX - iniX;
+        pitch = (tw + 3) & ~3;
+        xo = 0;
+        const int recip = (65536 + tw - 1) / tw;
+        for (int i = lane; i < tw * th; i += 64) {
+            const int y = div_small(i, recip);
+            const int x = i - y * tw;
+            tile[y * pitch + x] = img[(long long)(iniY + y) * rowStride + iniX + x];
+        }
+    }
+    uint8_t* score = smem + g.maxTileBytes;            // (sw+2) x (sh+2), zero ring
+    uint16_t* queue = reinterpret_cast<uint16_t*>(score + g.maxScoreBytes);
+    const int sp = sw + 2;
+    {
+        uint32_t* s32 = reinterpret_cast<uint32_t*>(score);
+        const int ndw = (sp * (sh + 2) + 3) >> 2;
+        for (int i = lane; i < ndw; i += 64) s32[i] = 0;
+    }
+    __syncthreads();
+
+    // ---- 2. cheap test at the low threshold, queue survivors in row-major order ----
+    const int npix = sw * sh;
+    const int recipSw = (65536 + sw - 1) / sw;
+    const int tlow = min(iniTh, minTh);
+    int nq = 0;
+    for (int base = 0; base < npix; base += 64) {
+        const int i = base + lane;
+        bool pass = false;
+        if (i < npix) {
+            const int y = div_small(i, recipSw);
+            const int x = i - y * sw;
+            const uint8_t* p = tile + (y + 3) * pitch + xo + x + 3;
+            const int v = p[0];
+            // circle pixel k and its antipode k+8: a run of 9 holds at least one of each pair
+            const int p0 = p[3 * pitch], p8 = p[-3 * pitch];
+            const int p4 = p[3], p12 = p[-3];
+            int mnmax = max(min(p0, p8), min(p4, p12));  // all pairs have a pixel < v-t  <=>  this < v-t
+            int mxmin = min(max(p0, p8), max(p4, p12));  // all pairs have a pixel > v+t  <=>  this > v+t
+            if (mnmax < v - tlow || mxmin > v + tlow) {
+                const int p1 = p[3 * pitch + 1], p9 = p[-3 * pitch - 1];
+                const int p2 = p[2 * pitch + 2], p10 = p[-2 * pitch - 2];
+                const int p3 = p[pitch + 3], p11 = p[-pitch - 3];
+                const int p5 = p[-pitch + 3], p13 = p[pitch - 3];
+                const int p6 = p[-2 * pitch + 2], p14 = p[2 * pitch - 2];
+                const int p7 = p[-3 * pitch + 1], p15 = p[3 * pitch - 1];
+                mnmax = max(mnmax, max(max(min(p1, p9), min(p2, p10)), max(min(p3, p11), min(p5, p13))));
+                mnmax = max(mnmax, max(min(p6, p14), min(p7, p15)));
+                mxmin = min(mxmin, min(min(max(p1, p9), max(p2, p10)), min(max(p3, p11), max(p5, p13))));
+                mxmin = min(mxmin, min(max(p6, p14), max(p7, p15)));
+                pass = mnmax < v - tlow || mxmin > v + tlow;
+            }
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) queue[nq + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+        nq += __popcll(m);
+    }
+    __syncthreads();
+
+    // ---- 3. exact corner strength for queued pixels; keep corners (S > tlow) in order ----
+    int nc = 0;
+    for (int base = 0; base < nq; base += 64) {
+        const int qi = base + lane;
+        int i = 0, S = 0;
+        if (qi < nq) {
+            i = queue[qi];
+            const int y = div_small(i, recipSw);
+            const int x = i - y * sw;
+            S = corner_strength(tile + (y + 3) * pitch + xo + x + 3, pitch);
+            if (S > tlow) score[(y + 1) * sp + x + 1] = (uint8_t)S; else S = 0;
+        }
+        const unsigned long long m = __ballot(S > 0);
+        // in-place compaction: position nc+prefix <= qi, and every lane has read queue[qi] above
+        if (S > 0) queue[nc + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+        nc += __popcll(m);
+    }
+    __syncthreads();
+
+    // ---- 4. suppression + ordered output, iniTh first, minTh if the cell stays empty ----
+    int nout = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int t = pass == 0 ? iniTh : minTh;
+        for (int base = 0; base < nc; base += 64) {
+            const int qi = base + lane;
+            bool keep = false;
+            int x = 0, y = 0, sc = 0;
+            if (qi < nc) {
+                const int i = queue[qi];
+                y = div_small(i, recipSw);
+                x = i - y * sw;
+                const uint8_t* s = score + (y + 1) * sp + x + 1;
+                const int S = s[0];
+                if (S > t) {
+                    sc = S - 1;
+                    int nb = max(max(s[-1], s[1]), max(max(s[-sp - 1], s[-sp]), s[-sp + 1]));
+                    nb = max(nb, max(max(s[sp - 1], s[sp]), s[sp + 1]));
+                    // neighbours that are not corners at this threshold count as score 0
+                    const int nbScore = nb > t ? nb - 1 : 0;
+                    keep = sc > nbScore;
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int pos = nout + __popcll(m & ((1ull << lane) - 1));
+                // FAST reports sub-image coordinates (x+3, y+3); the caller adds j*wCell, i*hCell (:814-815)
+                if (pos < L.slotCap) slotOut[pos] = pack_cand(cj * L.wCell + x + 3, ci * L.hCell + y + 3, sc);
+            }
+            nout += __popcll(m);
+        }
+        if (nout > 0 || iniTh == minTh) break;
+    }
+    if (lane == 0) *countOut = min(nout, L.slotCap);
+}
+
+hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nframes, int iniTh, int minTh,
+                             hipStream_t s) {
+    if (g.totalCells == 0) return hipSuccess;
+    const size_t lds = (size_t)g.maxTileBytes + g.maxScoreBytes + 2 * (size_t)g.maxScanPix + 16;
+    dim3 grid(g.totalCells, nframes, 1), block(64, 1, 1);
+    const bool aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
+    if (aligned)
+        hipLaunchKernelGGL(fast_cells_kernel<true>, grid, block, lds, s, fs, g, iniTh, minTh);
+    else
+        hipLaunchKernelGGL(fast_cells_kernel<false>, grid, block, lds, s, fs, g, iniTh, minTh);
+    return hipGetLastError();
+}
+
+}  // namespace orbx

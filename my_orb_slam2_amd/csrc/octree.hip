@@ -1,0 +1,332 @@
+// Quadtree keypoint distribution (ORBextractor::DistributeOctTree and ExtractorNode::DivideNode,
+// src/ORBextractor.cc:473-755), one 256-thread workgroup per (frame, level).
+//
+// The reference keeps a std::list of nodes, each owning a vector of keypoints, and splits nodes
+// one at a time. Here candidates never move: each carries the index of the node that owns it, and
+// a node's position in the array IS its position in the reference's list. One "round" is either a
+// full sweep of the reference's outer loop (:598-657) or one pass of its size-ordered loop
+// (:668-729); both have the same shape:
+//   - every node with more than one point is a split candidate;
+//   - they are processed in list order (sweep) or by point count descending, ties in list order
+//     (the reference sorts (count, node address) ascending and walks backwards, :676-677; the
+//     address is replaced by creation order, and since new nodes are pushed to the front, "newest
+//     first" is list order);
+//   - processing stops once the list holds N nodes (only in the size-ordered loop, :722-723);
+//   - each processed node is replaced by its non-empty children n1..n4, pushed to the front of the
+//     list one by one (:612-652), so the new list is: all children in reverse creation order,
+//     then the surviving old nodes in their old order.
+// Child point counts of every candidate are counted speculatively (LDS atomics), prefix sums give
+// the stopping point and every node's new position, and a second pass over the points re-labels
+// them. Finally each node emits its strongest point, first one on ties (:736-752).
+#include "orbx_internal.h"
+
+namespace orbx {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kLdsPoints = 6144;  // candidates of one level held in LDS; more spill to global memory
+
+// Inclusive scan of data[0..n) in place. `part` holds kThreads ints. All threads must call.
+__device__ void block_scan_inclusive(int* data, int n, int* part) {
+    const int t = threadIdx.x;
+    const int per = (n + kThreads - 1) / kThreads;
+    const int b = t * per, e = min(b + per, n);
+    int s = 0;
+    for (int i = b; i < e; i++) s += data[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < kThreads; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = t ? part[t - 1] : 0;
+    for (int i = b; i < e; i++) {
+        run += data[i];
+        data[i] = run;
+    }
+    __syncthreads();
+}
+
+struct Nodes {
+    short* x0;
+    short* y0;
+    short* x1;
+    short* y1;
+    int* cnt;
+};
+
+__device__ __forceinline__ int quadrant(uint32_t c, const Nodes& nd, int n) {
+    const int xm = nd.x0[n] + ((nd.x1[n] - nd.x0[n] + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2) (:475)
+    const int ym = nd.y0[n] + ((nd.y1[n] - nd.y0[n] + 1) >> 1);
+    return (cand_x(c) < xm ? 0 : 1) + (cand_y(c) < ym ? 0 : 2);   // n1, n2, n3, n4 (:507-517)
+}
+
+// The whole selection for one level, with candidates at `cand` / `nid` (LDS or global).
+__device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom& L, int nodeCap,
+                           uint8_t* lds, uint32_t* selOut, int32_t* selCountOut) {
+    const int t = threadIdx.x;
+    const int N = L.quota;
+    // ---- carve LDS ----
+    Nodes A, B;
+    short* sp = reinterpret_cast<short*>(lds);
+    A.x0 = sp; A.y0 = sp + nodeCap; A.x1 = sp + 2 * nodeCap; A.y1 = sp + 3 * nodeCap;
+    B.x0 = sp + 4 * nodeCap; B.y0 = sp + 5 * nodeCap; B.x1 = sp + 6 * nodeCap; B.y1 = sp + 7 * nodeCap;
+    short* childPos = sp + 8 * nodeCap;              // [node][4]
+    int* ip = reinterpret_cast<int*>(sp + 12 * nodeCap);
+    A.cnt = ip; B.cnt = ip + nodeCap;
+    int* cc = ip + 2 * nodeCap;                      // [node][4] speculative child counts
+    int* rank = ip + 6 * nodeCap;                    // processing rank of a split candidate
+    int* order = ip + 7 * nodeCap;                   // node at processing rank r
+    int* sinc = ip + 8 * nodeCap;                    // inclusive sum of (children - 1) in processing order
+    int* keptPos = ip + 9 * nodeCap;                 // scan of surviving old nodes / new position
+    int* part = ip + 10 * nodeCap;                   // kThreads ints of scan scratch
+    int* sh = part + kThreads;                       // small shared scalars
+    // sh[0]=nsplit sh[1]=m sh[2]=nExp
+
+    // ---- root nodes (:544-577) ----
+    const int nIni = L.nIni;
+    const int height = (L.h - kBorder) - kBorder;
+    for (int i = t; i < nIni; i += kThreads) {
+        B.x0[i] = (short)(int)(L.hX * (float)i);
+        B.x1[i] = (short)(int)(L.hX * (float)(i + 1));
+        B.y0[i] = 0;
+        B.y1[i] = (short)height;
+        B.cnt[i] = 0;
+    }
+    __syncthreads();
+    for (int p = t; p < P; p += kThreads) {
+        int r = (int)((float)cand_x(cand[p]) / L.hX);
+        r = min(max(r, 0), nIni - 1);
+        nid[p] = (uint16_t)r;
+        atomicAdd(&B.cnt[r], 1);
+    }
+    __syncthreads();
+    // drop empty roots, keep order
+    for (int i = t; i < nIni; i += kThreads) keptPos[i] = B.cnt[i] > 0 ? 1 : 0;
+    __syncthreads();
+    block_scan_inclusive(keptPos, nIni, part);
+    int Lc = nIni ? keptPos[nIni - 1] : 0;
+    for (int i = t; i < nIni; i += kThreads) {
+        if (B.cnt[i] > 0) {
+            const int pos = keptPos[i] - 1;
+            A.x0[pos] = B.x0[i]; A.y0[pos] = B.y0[i]; A.x1[pos] = B.x1[i]; A.y1[pos] = B.y1[i];
+            A.cnt[pos] = B.cnt[i];
+        }
+    }
+    __syncthreads();
+    for (int p = t; p < P; p += kThreads) nid[p] = (uint16_t)(keptPos[nid[p]] - 1);
+    __syncthreads();
+
+    Nodes cur = A, nxt = B;
+    bool careful = false;
+    for (int round = 0; round < 4096; round++) {
+        // ---- speculative child counts of every split candidate ----
+        for (int i = t; i < 4 * Lc; i += kThreads) cc[i] = 0;
+        __syncthreads();
+        for (int p = t; p < P; p += kThreads) {
+            const int n = nid[p];
+            if (cur.cnt[n] > 1) atomicAdd(&cc[4 * n + quadrant(cand[p], cur, n)], 1);
+        }
+        __syncthreads();
+        // ---- processing order ----
+        if (!careful) {
+            for (int i = t; i < Lc; i += kThreads) rank[i] = cur.cnt[i] > 1 ? 1 : 0;
+            __syncthreads();
+            block_scan_inclusive(rank, Lc, part);   // rank[i]-1 = position among candidates, list order
+            if (t == 0) sh[1] = Lc ? rank[Lc - 1] : 0;
+            __syncthreads();
+            for (int i = t; i < Lc; i += kThreads)
+                if (cur.cnt[i] > 1) { rank[i] -= 1; order[rank[i]] = i; }
+        } else {
+            if (t == 0) sh[1] = 0;
+            __syncthreads();
+            for (int i = t; i < Lc; i += kThreads) {
+                const int ci = cur.cnt[i];
+                if (ci > 1) {
+                    int r = 0;
+                    for (int j = 0; j < Lc; j++) {
+                        const int cj = cur.cnt[j];
+                        r += (cj > 1 && (cj > ci || (cj == ci && j < i))) ? 1 : 0;
+                    }
+                    rank[i] = r;
+                    order[r] = i;
+                    atomicAdd(&sh[1], 1);
+                }
+            }
+        }
+        __syncthreads();
+        const int m = sh[1];
+        // ---- how many candidates are actually split ----
+        for (int r = t; r < m; r += kThreads) {
+            const int* c4 = cc + 4 * order[r];
+            sinc[r] = (c4[0] > 0) + (c4[1] > 0) + (c4[2] > 0) + (c4[3] > 0) - 1;
+        }
+        __syncthreads();
+        block_scan_inclusive(sinc, m, part);
+        if (t == 0) sh[0] = m;
+        __syncthreads();
+        if (careful) {
+            for (int r = t; r < m; r += kThreads)
+                if (Lc + sinc[r] >= N && (r == 0 || Lc + sinc[r - 1] < N)) sh[0] = r + 1;  // first rank reaching N
+            __syncthreads();
+        }
+        const int nsplit = sh[0];
+        const int C = nsplit > 0 ? sinc[nsplit - 1] + nsplit : 0;   // children created this round
+        const int Lnew = Lc - nsplit + C;
+        if (Lnew > nodeCap) {  // cannot happen (Lnew <= max(N+3, 4*nIni)); never write out of bounds
+            if (t == 0) *selCountOut = 0;
+            return;
+        }
+        // ---- new node table ----
+        for (int i = t; i < Lc; i += kThreads) keptPos[i] = (cur.cnt[i] > 1 && rank[i] < nsplit) ? 0 : 1;
+        __syncthreads();
+        block_scan_inclusive(keptPos, Lc, part);
+        if (t == 0) sh[2] = 0;
+        __syncthreads();
+        for (int i = t; i < Lc; i += kThreads) {
+            const bool split = cur.cnt[i] > 1 && rank[i] < nsplit;
+            if (!split) {
+                const int pos = C + keptPos[i] - 1;
+                nxt.x0[pos] = cur.x0[i]; nxt.y0[pos] = cur.y0[i]; nxt.x1[pos] = cur.x1[i]; nxt.y1[pos] = cur.y1[i];
+                nxt.cnt[pos] = cur.cnt[i];
+                keptPos[i] = pos;
+            } else {
+                const int r = rank[i];
+                int k = r > 0 ? sinc[r - 1] + r : 0;   // creation index of this node's first child
+                const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
+                const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1);
+                int nExp = 0;
+                for (int q = 0; q < 4; q++) {
+                    const int cq = cc[4 * i + q];
+                    if (cq == 0) continue;
+                    const int pos = C - 1 - k;           // each child is pushed to the front
+                    k++;
+                    nxt.x0[pos] = (short)((q & 1) ? xm : x0);
+                    nxt.x1[pos] = (short)((q & 1) ? x1 : xm);
+                    nxt.y0[pos] = (short)((q & 2) ? ym : y0);
+                    nxt.y1[pos] = (short)((q & 2) ? y1 : ym);
+                    nxt.cnt[pos] = cq;
+                    childPos[4 * i + q] = (short)pos;
+                    nExp += cq > 1;
+                }
+                keptPos[i] = -1;
+                if (nExp) atomicAdd(&sh[2], nExp);
+            }
+        }
+        __syncthreads();
+        // ---- re-label the points ----
+        for (int p = t; p < P; p += kThreads) {
+            const int n = nid[p];
+            const int kp = keptPos[n];
+            nid[p] = (uint16_t)(kp >= 0 ? kp : childPos[4 * n + quadrant(cand[p], cur, n)]);
+        }
+        __syncthreads();
+        const int nExp = sh[2];
+        const Nodes tmp = cur; cur = nxt; nxt = tmp;
+        const bool done = Lnew >= N || Lnew == Lc;     // (:661, :726)
+        if (!careful && !done && Lnew + 3 * nExp > N) careful = true;   // (:665)
+        Lc = Lnew;
+        __syncthreads();
+        if (done) break;
+    }
+
+    // ---- strongest point of every node, first one on ties (:736-752) ----
+    int* best = cc;
+    for (int i = t; i < Lc; i += kThreads) best[i] = 0;
+    __syncthreads();
+    for (int p = t; p < P; p += kThreads)
+        atomicMax(reinterpret_cast<unsigned*>(&best[nid[p]]),
+                  ((unsigned)cand_score(cand[p]) << 24) | (0xFFFFFFu - (unsigned)p));
+    __syncthreads();
+    for (int i = t; i < Lc; i += kThreads) {
+        const unsigned p = 0xFFFFFFu - ((unsigned)best[i] & 0xFFFFFFu);
+        if (i < N + kSelPad) selOut[i] = cand[p];
+    }
+    if (t == 0) *selCountOut = min(Lc, N + kSelPad);
+}
+
+}  // namespace
+
+size_t octree_lds_bytes(const PyramidGeom& g) {
+    // 12 shorts + 10 ints per node, scan scratch, scalars, then the LDS candidate arrays
+    return (size_t)g.nodeCap * (12 * 2 + 10 * 4) + (kThreads + 8) * 4 + 16 +
+           (size_t)kLdsPoints * (4 + 2);
+}
+
+__global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGeom g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int t = threadIdx.x;
+    const int l = blockIdx.x, f = blockIdx.y;
+    const LevelGeom& L = g.lv[l];
+    uint32_t* selOut = fs.sel + (long long)f * g.totalSel + L.selBase;
+    int32_t* selCountOut = fs.selCount + (long long)f * g.nlevels + l;
+    const int nCells = L.nCols * L.nRows;
+    if (nCells == 0 || L.quota <= 0) {
+        if (t == 0) *selCountOut = 0;
+        return;
+    }
+    // ---- gather the level's candidates in the reference's order: cells row-major (:781-821) ----
+    const size_t nodeBytes = ((size_t)g.nodeCap * (12 * 2 + 10 * 4) + (kThreads + 8) * 4 + 15) & ~(size_t)15;
+    int* part = reinterpret_cast<int*>(smem);            // scan scratch, reused by distribute()
+    const int32_t* counts = fs.cellCount + (long long)f * g.totalCells + L.cellBase;
+    const uint32_t* slots = fs.slots + (long long)f * g.totalSlots + L.slotBase;
+    const int per = (nCells + kThreads - 1) / kThreads;
+    const int cb = min(t * per, nCells), ce = min(cb + per, nCells);
+    int mine = 0;
+    for (int c = cb; c < ce; c++) mine += counts[c];
+    __syncthreads();
+    part[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < kThreads; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const int P = part[kThreads - 1];
+    int dst = part[t] - mine;
+    __syncthreads();
+    if (P == 0) {
+        if (t == 0) *selCountOut = 0;
+        return;
+    }
+    uint32_t* cand;
+    uint16_t* nid;
+    const bool inLds = P <= kLdsPoints;
+    if (inLds) {
+        cand = reinterpret_cast<uint32_t*>(smem + nodeBytes);
+        nid = reinterpret_cast<uint16_t*>(smem + nodeBytes + (size_t)kLdsPoints * 4);
+    } else {
+        cand = fs.cand + (long long)f * g.totalSlots + L.slotBase;
+        nid = fs.nid + (long long)f * g.totalSlots + L.slotBase;
+    }
+    for (int c = cb; c < ce; c++) {
+        const int n = counts[c];
+        const uint32_t* src = slots + (long long)c * L.slotCap;
+        for (int k = 0; k < n; k++) cand[dst++] = src[k];
+    }
+    __syncthreads();
+    if (inLds)
+        distribute(cand, nid, P, L, g.nodeCap, smem, selOut, selCountOut);
+    else
+        distribute(cand, nid, P, L, g.nodeCap, smem, selOut, selCountOut);
+}
+
+hipError_t launch_octree(const FrameSet& fs, const PyramidGeom& g, int nframes, hipStream_t s) {
+    dim3 grid(g.nlevels, nframes, 1), block(kThreads, 1, 1);
+    const size_t lds = octree_lds_bytes(g);
+    static bool attrSet = false;
+    if (!attrSet && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attrSet = true;
+    }
+    hipLaunchKernelGGL(octree_kernel, grid, block, lds, s, fs, g);
+    return hipGetLastError();
+}
+
+}  // namespace orbx

@@ -1,0 +1,635 @@
+// C ABI of liborbx (include/orbx.h): context management, buffer layout and kernel sequencing.
+// Host code only; kernels live in pyramid.hip, fast_cells.hip, octree.hip, orient_desc.hip and
+// match.hip. There is no CPU fallback: without a usable HIP device every compute entry point
+// returns ORBX_ERR_HIP.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "orbx_internal.h"
+
+using namespace orbx;
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,  \
+                      __LINE__);                                                        \
+            return ORBX_ERR_HIP;                                                        \
+        }                                                                               \
+    } while (0)
+
+struct orbx_ctx {
+    orbx_config cfg;
+    ScaleTables tab;
+    hipStream_t stream = nullptr;
+    // geometry of the image size seen last
+    PyramidGeom geom;
+    bool haveGeom = false;
+    ResizeTab resize[ORBX_MAX_LEVELS];
+    void* resizeBlob = nullptr;
+    // device buffers sized for max_width x max_height x max_batch
+    PyramidGeom maxGeom;
+    FrameSet fs;
+    uint8_t* stageImg = nullptr;        // H2D staging of host frames
+    orbx_keypoint* stageKps = nullptr;  // device outputs of the host-buffer entry points
+    uint8_t* stageDesc = nullptr;
+    int32_t* stageCounts = nullptr;
+    int stageCap = 0;
+    // last call
+    int lastFrames = 0;
+    hipStream_t lastStream = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(count * sizeof(T), 256)));
+    *p = static_cast<T*>(q);
+    return ORBX_OK;
+}
+
+int ensure_geometry(orbx_ctx* c, int w, int h) {
+    if (c->haveGeom && c->geom.width == w && c->geom.height == h) return ORBX_OK;
+    std::string err;
+    PyramidGeom g;
+    if (!build_geometry(w, h, c->tab, g, err)) {
+        set_error("%s", err.c_str());
+        return ORBX_ERR_INVALID;
+    }
+    if (g.totalCells > c->maxGeom.totalCells || g.totalSlots > c->maxGeom.totalSlots ||
+        g.pyrBytes > c->maxGeom.pyrBytes || w > c->cfg.max_width || h > c->cfg.max_height) {
+        set_error("image %dx%d exceeds the context's maximum %dx%d", w, h, c->cfg.max_width,
+                  c->cfg.max_height);
+        return ORBX_ERR_INVALID;
+    }
+    // resize tables for levels 1..n-1, one blob
+    std::vector<HostResizeTab> ht(g.nlevels);
+    size_t bytes = 0;
+    auto up = [](size_t v) { return (v + 63) / 64 * 64; };
+    for (int l = 1; l < g.nlevels; l++) {
+        build_resize_table(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h, ht[l]);
+        bytes += up(ht[l].xofs.size() * 4) + up(ht[l].yofs.size() * 4) + up(ht[l].ialpha.size() * 2) +
+                 up(ht[l].ibeta.size() * 2);
+    }
+    std::vector<uint8_t> blob(std::max<size_t>(bytes, 64));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the old tables may still be in use
+    if (c->resizeBlob) HIP_TRY(hipFree(c->resizeBlob));
+    c->resizeBlob = nullptr;
+    HIP_TRY(hipMalloc(&c->resizeBlob, blob.size()));
+    size_t off = 0;
+    uint8_t* dbase = static_cast<uint8_t*>(c->resizeBlob);
+    for (int l = 1; l < g.nlevels; l++) {
+        auto put = [&](const void* src, size_t n) {
+            std::memcpy(blob.data() + off, src, n);
+            const uint8_t* d = dbase + off;
+            off += up(n);
+            return d;
+        };
+        c->resize[l].xofs = reinterpret_cast<const int32_t*>(put(ht[l].xofs.data(), ht[l].xofs.size() * 4));
+        c->resize[l].yofs = reinterpret_cast<const int32_t*>(put(ht[l].yofs.data(), ht[l].yofs.size() * 4));
+        c->resize[l].ialpha = reinterpret_cast<const int16_t*>(put(ht[l].ialpha.data(), ht[l].ialpha.size() * 2));
+        c->resize[l].ibeta = reinterpret_cast<const int16_t*>(put(ht[l].ibeta.data(), ht[l].ibeta.size() * 2));
+        c->resize[l].xmax = ht[l].xmax;
+    }
+    HIP_TRY(hipMemcpy(c->resizeBlob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    c->geom = g;
+    c->haveGeom = true;
+    return ORBX_OK;
+}
+
+int check_ctx(const orbx_ctx* c) {
+    if (!c) {
+        set_error("null context");
+        return ORBX_ERR_INVALID;
+    }
+    return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" int orbx_create(const orbx_config* cfg, orbx_ctx** out) {
+    if (!cfg || !out) {
+        set_error("null argument");
+        return ORBX_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (cfg->nlevels < 1 || cfg->nlevels > ORBX_MAX_LEVELS || cfg->nfeatures < 1 ||
+        !(cfg->scale_factor > 1.0f) || cfg->max_width < 1 || cfg->max_height < 1 || cfg->max_batch < 1 ||
+        cfg->max_width > 4096 || cfg->max_height > 4096 || cfg->ini_th_fast < 1 || cfg->min_th_fast < 1 ||
+        cfg->ini_th_fast > 255 || cfg->min_th_fast > 255 ||
+        (cfg->blur_taps != ORBX_BLUR_CV_4_0_0 && cfg->blur_taps != ORBX_BLUR_CV_4_2_PLUS)) {
+        set_error("invalid orbx_config");
+        return ORBX_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(cfg->device));
+    orbx_ctx* c = new (std::nothrow) orbx_ctx();
+    if (!c) {
+        set_error("out of host memory");
+        return ORBX_ERR_INVALID;
+    }
+    c->cfg = *cfg;
+    build_scale_tables(cfg->nfeatures, cfg->scale_factor, cfg->nlevels, c->tab);
+    std::string err;
+    if (!build_geometry(cfg->max_width, cfg->max_height, c->tab, c->maxGeom, err)) {
+        set_error("%s", err.c_str());
+        delete c;
+        return ORBX_ERR_INVALID;
+    }
+    if (octree_lds_bytes(c->maxGeom) > 160 * 1024) {
+        set_error("nfeatures too large for the quadtree's LDS node table");
+        delete c;
+        return ORBX_ERR_INVALID;
+    }
+    // Cell grids are not monotone in the image size (wCell = ceil(width / nCols)), so leave head
+    // room: smaller images can have a few more cells or larger per-cell slot capacities.
+    PyramidGeom& mg = c->maxGeom;
+    mg.totalCells = mg.totalCells + mg.totalCells / 4 + 64;
+    mg.totalSlots = mg.totalSlots + mg.totalSlots / 2 + 4096;
+    mg.pyrBytes += 4096;
+    const size_t B = (size_t)cfg->max_batch;
+    int rc = ORBX_OK;
+    auto fail = [&](int code) {
+        orbx_destroy(c);
+        return code;
+    };
+    hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(he));
+        return fail(ORBX_ERR_HIP);
+    }
+    if ((rc = dev_alloc(&c->fs.pyr, B * (size_t)mg.pyrBytes))) return fail(rc);
+    if ((rc = dev_alloc(&c->fs.cellCount, B * (size_t)mg.totalCells))) return fail(rc);
+    if ((rc = dev_alloc(&c->fs.slots, B * (size_t)mg.totalSlots))) return fail(rc);
+    if ((rc = dev_alloc(&c->fs.cand, B * (size_t)mg.totalSlots))) return fail(rc);
+    if ((rc = dev_alloc(&c->fs.nid, B * (size_t)mg.totalSlots))) return fail(rc);
+    if ((rc = dev_alloc(&c->fs.sel, B * (size_t)mg.totalSel))) return fail(rc);
+    if ((rc = dev_alloc(&c->fs.selCount, B * (size_t)cfg->nlevels))) return fail(rc);
+    *out = c;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_destroy(orbx_ctx* c) {
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* bufs[] = {c->fs.pyr, c->fs.cellCount, c->fs.slots, c->fs.cand, c->fs.nid, c->fs.sel,
+                    c->fs.selCount, c->resizeBlob, c->stageImg, c->stageKps, c->stageDesc, c->stageCounts};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int orbx_get_levels(const orbx_ctx* c) { return c ? c->cfg.nlevels : 0; }
+extern "C" float orbx_get_scale_factor(const orbx_ctx* c) { return c ? c->cfg.scale_factor : 0.f; }
+#define ORBX_GETTER(name, field)                                          \
+    extern "C" int name(const orbx_ctx* c, float* out) {                  \
+        if (!c || !out) return ORBX_ERR_INVALID;                          \
+        std::copy(c->tab.field.begin(), c->tab.field.end(), out);         \
+        return ORBX_OK;                                                   \
+    }
+ORBX_GETTER(orbx_get_scale_factors, scale)
+ORBX_GETTER(orbx_get_inverse_scale_factors, invScale)
+ORBX_GETTER(orbx_get_scale_sigma_squares, sigma2)
+ORBX_GETTER(orbx_get_inverse_scale_sigma_squares, invSigma2)
+extern "C" int orbx_get_features_per_level(const orbx_ctx* c, int32_t* out) {
+    if (!c || !out) return ORBX_ERR_INVALID;
+    std::copy(c->tab.perLevel.begin(), c->tab.perLevel.end(), out);
+    return ORBX_OK;
+}
+extern "C" int orbx_get_umax(const orbx_ctx* c, int32_t* out16) {
+    if (!c || !out16) return ORBX_ERR_INVALID;
+    std::copy(c->tab.umax, c->tab.umax + kHalfPatch + 1, out16);
+    return ORBX_OK;
+}
+extern "C" int orbx_keypoint_capacity(const orbx_ctx* c) {
+    if (!c) return 0;
+    int cap = 0;
+    for (int q : c->tab.perLevel) cap += q + 3;
+    return cap;
+}
+
+extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, int nframes, int width,
+                                         int height, size_t row_stride, size_t frame_stride,
+                                         orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts,
+                                         void* stream) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (nframes == 0) return ORBX_OK;
+    if (!d_images || !d_kps || !d_desc || !d_counts || nframes < 0 || nframes > c->cfg.max_batch ||
+        width < 1 || height < 1 || row_stride < (size_t)width || cap < 1 ||
+        (nframes > 1 && frame_stride < row_stride * (size_t)(height - 1) + (size_t)width)) {
+        set_error("orbx_extract_batch_device: bad argument (nframes %d of max %d, %dx%d, cap %d)", nframes,
+                  c->cfg.max_batch, width, height, cap);
+        return ORBX_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if ((rc = ensure_geometry(c, width, height))) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    FrameSet fs = c->fs;
+    fs.img = d_images;
+    fs.imgRowStride = (long long)row_stride;
+    fs.imgFrameStride = (long long)frame_stride;
+    c->fs = fs;
+    c->lastFrames = nframes;
+    c->lastStream = s;
+    const PyramidGeom& g = c->geom;
+    HIP_TRY(launch_pyramid(fs, g, c->resize, nframes, s));
+    HIP_TRY(launch_fast_cells(fs, g, nframes, c->cfg.ini_th_fast, c->cfg.min_th_fast, s));
+    HIP_TRY(launch_octree(fs, g, nframes, s));
+    HIP_TRY(launch_orient_desc(fs, g, nframes, c->cfg.blur_taps, d_kps, d_desc, cap, d_counts, s));
+    return ORBX_OK;
+}
+
+namespace {
+int ensure_staging(orbx_ctx* c, int cap) {
+    const size_t B = (size_t)c->cfg.max_batch;
+    if (!c->stageImg) {
+        int rc = dev_alloc(&c->stageImg, B * (size_t)c->cfg.max_width * c->cfg.max_height);
+        if (rc) return rc;
+        if ((rc = dev_alloc(&c->stageCounts, B))) return rc;
+    }
+    if (cap > c->stageCap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->stageKps) HIP_TRY(hipFree(c->stageKps));
+        if (c->stageDesc) HIP_TRY(hipFree(c->stageDesc));
+        c->stageKps = nullptr;
+        c->stageDesc = nullptr;
+        c->stageCap = 0;
+        int rc = dev_alloc(&c->stageKps, B * (size_t)cap);
+        if (rc) return rc;
+        if ((rc = dev_alloc(&c->stageDesc, B * (size_t)cap * ORBX_DESC_BYTES))) return rc;
+        c->stageCap = cap;
+    }
+    return ORBX_OK;
+}
+}  // namespace
+
+extern "C" int orbx_extract_batch(orbx_ctx* c, const uint8_t* images, int nframes, int width, int height,
+                                  size_t row_stride, size_t frame_stride, orbx_keypoint* kps, uint8_t* desc,
+                                  int cap, int32_t* counts) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (nframes == 0) return ORBX_OK;
+    if (!images || !kps || !desc || !counts || nframes < 0 || nframes > c->cfg.max_batch || width < 1 ||
+        height < 1 || width > c->cfg.max_width || height > c->cfg.max_height || row_stride < (size_t)width ||
+        cap < 1) {
+        set_error("orbx_extract_batch: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if ((rc = ensure_staging(c, cap))) return rc;
+    // frames are packed on the device with a 4-byte-multiple pitch
+    const size_t pitch = ((size_t)width + 3) & ~(size_t)3;
+    const size_t fstride = pitch * (size_t)height;
+    for (int f = 0; f < nframes; f++)
+        HIP_TRY(hipMemcpy2DAsync(c->stageImg + f * fstride, pitch, images + f * frame_stride, row_stride,
+                                 (size_t)width, (size_t)height, hipMemcpyHostToDevice, c->stream));
+    rc = orbx_extract_batch_device(c, c->stageImg, nframes, width, height, pitch, fstride, c->stageKps,
+                                   c->stageDesc, cap, c->stageCounts, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(counts, c->stageCounts, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(kps, c->stageKps, sizeof(orbx_keypoint) * (size_t)nframes * cap,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(desc, c->stageDesc, (size_t)ORBX_DESC_BYTES * nframes * cap, hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract(orbx_ctx* c, const uint8_t* image, int width, int height, size_t stride,
+                            orbx_keypoint* kps, uint8_t* desc, int cap, int* n) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!image || width <= 0 || height <= 0) return ORBX_OK;   // empty image: outputs untouched
+    if (!n) {
+        set_error("orbx_extract: null count pointer");
+        return ORBX_ERR_INVALID;
+    }
+    int32_t count = 0;
+    rc = orbx_extract_batch(c, image, 1, width, height, stride, stride * (size_t)height, kps, desc, cap, &count);
+    if (rc) return rc;
+    *n = count;
+    if (count > cap) {
+        set_error("orbx_extract: %d keypoints found, capacity %d", count, cap);
+        return ORBX_ERR_CAPACITY;
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_synchronize(orbx_ctx* c) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->lastStream && c->lastStream != c->stream) HIP_TRY(hipStreamSynchronize(c->lastStream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_level_size(const orbx_ctx* c, int level, int* width, int* height) {
+    if (!c || !c->haveGeom || level < 0 || level >= c->geom.nlevels || !width || !height) {
+        set_error("orbx_level_size: no geometry yet or bad level");
+        return ORBX_ERR_STATE;
+    }
+    *width = c->geom.lv[level].w;
+    *height = c->geom.lv[level].h;
+    return ORBX_OK;
+}
+
+namespace {
+int check_probe(orbx_ctx* c, int frame, int level) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!c->haveGeom || c->lastFrames == 0 || frame < 0 || frame >= c->lastFrames || level < 0 ||
+        level >= c->geom.nlevels) {
+        set_error("probe: frame %d / level %d not available", frame, level);
+        return ORBX_ERR_STATE;
+    }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->lastStream));
+    return ORBX_OK;
+}
+
+void level_ptr(const orbx_ctx* c, int frame, int level, const uint8_t** p, size_t* stride) {
+    const PyramidGeom& g = c->geom;
+    if (level == 0) {
+        *p = c->fs.img + (size_t)frame * c->fs.imgFrameStride;
+        *stride = (size_t)c->fs.imgRowStride;
+    } else {
+        *p = c->fs.pyr + (size_t)frame * g.pyrBytes + g.lv[level].offset;
+        *stride = (size_t)g.lv[level].stride;
+    }
+}
+
+inline int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+}  // namespace
+
+extern "C" int orbx_get_level(orbx_ctx* c, int frame, int level, int border, uint8_t* dst, size_t dst_stride) {
+    int rc = check_probe(c, frame, level);
+    if (rc) return rc;
+    const LevelGeom& L = c->geom.lv[level];
+    if (!dst || L.w < 1 || L.h < 1) {
+        set_error("orbx_get_level: null destination or empty level");
+        return ORBX_ERR_INVALID;
+    }
+    const uint8_t* src;
+    size_t stride;
+    level_ptr(c, frame, level, &src, &stride);
+    std::vector<uint8_t> tmp((size_t)L.w * L.h);
+    HIP_TRY(hipMemcpy2D(tmp.data(), (size_t)L.w, src, stride, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
+    if (!border) {
+        for (int y = 0; y < L.h; y++) std::memcpy(dst + (size_t)y * dst_stride, tmp.data() + (size_t)y * L.w, L.w);
+        return ORBX_OK;
+    }
+    // the 19-px BORDER_REFLECT_101 frame of src/ORBextractor.cc:1114-1120
+    for (int y = 0; y < L.h + 2 * kEdge; y++) {
+        const uint8_t* S = tmp.data() + (size_t)reflect101(y - kEdge, L.h) * L.w;
+        uint8_t* D = dst + (size_t)y * dst_stride;
+        for (int x = 0; x < L.w + 2 * kEdge; x++) D[x] = S[reflect101(x - kEdge, L.w)];
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_debug_blur_level(orbx_ctx* c, int frame, int level, uint8_t* dst, size_t dst_stride) {
+    int rc = check_probe(c, frame, level);
+    if (rc) return rc;
+    const LevelGeom& L = c->geom.lv[level];
+    if (!dst || L.w < 1 || L.h < 1) {
+        set_error("orbx_debug_blur_level: null destination or empty level");
+        return ORBX_ERR_INVALID;
+    }
+    const uint8_t* src;
+    size_t stride;
+    level_ptr(c, frame, level, &src, &stride);
+    uint8_t* tmp = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)L.w * L.h));
+    hipError_t e = launch_blur_level(src, L.w, L.h, (long long)stride, tmp, L.w, c->cfg.blur_taps, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2D(dst, dst_stride, tmp, (size_t)L.w, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    HIP_TRY(e);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_debug_candidates(orbx_ctx* c, int frame, int level, orbx_keypoint* out, int cap, int* n) {
+    int rc = check_probe(c, frame, level);
+    if (rc) return rc;
+    if (!n || (!out && cap > 0)) return ORBX_ERR_INVALID;
+    const PyramidGeom& g = c->geom;
+    const LevelGeom& L = g.lv[level];
+    const int nCells = L.nCols * L.nRows;
+    *n = 0;
+    if (nCells == 0) return ORBX_OK;
+    std::vector<int32_t> counts(nCells);
+    std::vector<uint32_t> slots((size_t)nCells * L.slotCap);
+    HIP_TRY(hipMemcpy(counts.data(), c->fs.cellCount + (size_t)frame * g.totalCells + L.cellBase,
+                      sizeof(int32_t) * nCells, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(slots.data(), c->fs.slots + (size_t)frame * g.totalSlots + L.slotBase,
+                      sizeof(uint32_t) * slots.size(), hipMemcpyDeviceToHost));
+    int k = 0;
+    for (int cell = 0; cell < nCells; cell++)
+        for (int i = 0; i < counts[cell]; i++, k++) {
+            if (k >= cap) continue;
+            const uint32_t p = slots[(size_t)cell * L.slotCap + i];
+            out[k] = orbx_keypoint{(float)cand_x(p), (float)cand_y(p), 7.f, -1.f, (float)cand_score(p), 0, -1};
+        }
+    *n = k;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_debug_selected(orbx_ctx* c, int frame, int level, orbx_keypoint* out, int cap, int* n) {
+    int rc = check_probe(c, frame, level);
+    if (rc) return rc;
+    if (!n || (!out && cap > 0)) return ORBX_ERR_INVALID;
+    const PyramidGeom& g = c->geom;
+    const LevelGeom& L = g.lv[level];
+    int32_t count = 0;
+    HIP_TRY(hipMemcpy(&count, c->fs.selCount + (size_t)frame * g.nlevels + level, sizeof(int32_t),
+                      hipMemcpyDeviceToHost));
+    std::vector<uint32_t> sel(std::max(count, 1));
+    HIP_TRY(hipMemcpy(sel.data(), c->fs.sel + (size_t)frame * g.totalSel + L.selBase, sizeof(uint32_t) * count,
+                      hipMemcpyDeviceToHost));
+    for (int i = 0; i < count && i < cap; i++)
+        out[i] = orbx_keypoint{(float)(cand_x(sel[i]) + kBorder), (float)(cand_y(sel[i]) + kBorder), L.kpSize,
+                               -1.f, (float)cand_score(sel[i]), level, -1};
+    *n = count;
+    return ORBX_OK;
+}
+
+// ---- matcher ------------------------------------------------------------------------------
+
+extern "C" int orbx_hamming256(const uint8_t* a, const uint8_t* b) {
+    int d = 0;
+    for (int i = 0; i < 4; i++) {
+        uint64_t x, y;
+        std::memcpy(&x, a + 8 * i, 8);
+        std::memcpy(&y, b + 8 * i, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+
+struct orbx_matcher {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void* scratch = nullptr;
+    size_t scratchBytes = 0;
+    float* scale = nullptr;   // device copy of the scale factors for the stereo search
+};
+
+namespace {
+int matcher_scratch(orbx_matcher* m, size_t bytes, hipStream_t s) {
+    if (bytes <= m->scratchBytes) return ORBX_OK;
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->scratch) HIP_TRY(hipFree(m->scratch));
+    m->scratch = nullptr;
+    m->scratchBytes = 0;
+    HIP_TRY(hipMalloc(&m->scratch, bytes));
+    m->scratchBytes = bytes;
+    return ORBX_OK;
+}
+}  // namespace
+
+extern "C" int orbx_matcher_create(int device, orbx_matcher** out) {
+    if (!out) return ORBX_ERR_INVALID;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    orbx_matcher* m = new (std::nothrow) orbx_matcher();
+    if (!m) return ORBX_ERR_INVALID;
+    m->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->scale), sizeof(float) * ORBX_MAX_LEVELS);
+    if (e != hipSuccess) {
+        set_error("orbx_matcher_create: %s", hipGetErrorString(e));
+        orbx_matcher_destroy(m);
+        return ORBX_ERR_HIP;
+    }
+    *out = m;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_matcher_destroy(orbx_matcher* m) {
+    if (!m) return;
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->scratch) (void)hipFree(m->scratch);
+    if (m->scale) (void)hipFree(m->scale);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int orbx_matcher_synchronize(orbx_matcher* m) {
+    if (!m) return ORBX_ERR_INVALID;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_hamming_knn2_device(orbx_matcher* m, const uint8_t* d_query, int64_t nq, const uint8_t* d_db,
+                                        int64_t ndb, int32_t init, int64_t db_index_base, int64_t* d_idx,
+                                        int32_t* d_d1, int32_t* d_d2, void* stream) {
+    if (!m || nq < 0 || ndb < 0 || ndb > INT32_MAX || (nq > 0 && (!d_query || !d_idx || !d_d1 || !d_d2)) ||
+        (ndb > 0 && !d_db) || ((uintptr_t)d_query % 16) || ((uintptr_t)d_db % 16)) {
+        set_error("orbx_hamming_knn2_device: bad argument (descriptor arrays must be 16-byte aligned)");
+        return ORBX_ERR_INVALID;
+    }
+    if (nq == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+    int rc = matcher_scratch(m, knn2_scratch_bytes(nq, ndb), s);
+    if (rc) return rc;
+    HIP_TRY(launch_knn2(d_query, nq, d_db, ndb, init, db_index_base, d_idx, d_d1, d_d2, m->scratch,
+                        m->scratchBytes, s));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_hamming_knn2(orbx_matcher* m, const uint8_t* query, int64_t nq, const uint8_t* db, int64_t ndb,
+                                 int32_t init, int64_t* idx, int32_t* d1, int32_t* d2) {
+    if (!m || nq < 0 || ndb < 0 || (nq > 0 && (!query || !idx || !d1 || !d2)) || (ndb > 0 && !db)) {
+        set_error("orbx_hamming_knn2: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (nq == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    uint8_t *dq = nullptr, *ddb = nullptr;
+    int64_t* didx = nullptr;
+    int32_t *dd1 = nullptr, *dd2 = nullptr;
+    int rc = ORBX_OK;
+    auto run = [&]() -> int {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dq), (size_t)nq * 32));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ddb), std::max<size_t>((size_t)ndb * 32, 32)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&didx), (size_t)nq * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dd1), (size_t)nq * 4));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dd2), (size_t)nq * 4));
+        HIP_TRY(hipMemcpyAsync(dq, query, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+        if (ndb) HIP_TRY(hipMemcpyAsync(ddb, db, (size_t)ndb * 32, hipMemcpyHostToDevice, m->stream));
+        int r = orbx_hamming_knn2_device(m, dq, nq, ddb, ndb, init, 0, didx, dd1, dd2, m->stream);
+        if (r) return r;
+        HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)nq * 8, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(d1, dd1, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(d2, dd2, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        return ORBX_OK;
+    };
+    rc = run();
+    void* bufs[] = {dq, ddb, didx, dd1, dd2};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+extern "C" int orbx_knn2_merge_device(orbx_matcher* m, int nparts, int64_t nq, const int64_t* d_idx,
+                                      const int32_t* d_d1, const int32_t* d_d2, int32_t init, int64_t* d_out_idx,
+                                      int32_t* d_out_d1, int32_t* d_out_d2, void* stream) {
+    if (!m || nparts < 1 || nq < 0 || (nq > 0 && (!d_idx || !d_d1 || !d_d2 || !d_out_idx || !d_out_d1 || !d_out_d2))) {
+        set_error("orbx_knn2_merge_device: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+    HIP_TRY(launch_knn2_merge(nparts, nq, d_idx, d_d1, d_d2, init, d_out_idx, d_out_d1, d_out_d2, s));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_ratio_test_device(orbx_matcher* m, int64_t nq, const int32_t* d_d1, const int32_t* d_d2,
+                                      int32_t th, int inclusive, float ratio, uint8_t* d_accept, void* stream) {
+    if (!m || nq < 0 || (nq > 0 && (!d_d1 || !d_d2 || !d_accept))) {
+        set_error("orbx_ratio_test_device: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+    HIP_TRY(launch_ratio_test(nq, d_d1, d_d2, th, inclusive, ratio, d_accept, s));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_stereo_band_match_device(orbx_matcher* m, int npairs, int cap, const orbx_keypoint* d_kl,
+                                             const uint8_t* d_dl, const int32_t* d_nl, const orbx_keypoint* d_kr,
+                                             const uint8_t* d_dr, const int32_t* d_nr, const float* scale_factors,
+                                             int nlevels, float bf, float b, int32_t* d_best_idx,
+                                             int32_t* d_best_dist, void* stream) {
+    if (!m || npairs < 0 || cap < 1 || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || !scale_factors || !(b > 0) ||
+        (npairs > 0 && (!d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_best_idx || !d_best_dist)) ||
+        ((uintptr_t)d_dl % 16) || ((uintptr_t)d_dr % 16)) {
+        set_error("orbx_stereo_band_match_device: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (npairs == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+    HIP_TRY(hipMemcpyAsync(m->scale, scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, s));
+    const float maxD = bf / b;   // mbf / minZ with minZ = mb (src/Frame.cc:533-535)
+    HIP_TRY(launch_stereo_band(npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, m->scale, nlevels, maxD,
+                               d_best_idx, d_best_dist, s));
+    return ORBX_OK;
+}

@@ -1,0 +1,127 @@
+// Internal declarations shared by the host side and the gfx950 kernels of liborbx.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "orbx.h"
+
+namespace orbx {
+
+constexpr int kEdge = 19;        // EDGE_THRESHOLD (src/ORBextractor.cc:66)
+constexpr int kBorder = 16;      // EDGE_THRESHOLD - 3: first column/row FAST may look at (:765)
+constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE (:65)
+constexpr int kPatchSize = 31;   // PATCH_SIZE (:64)
+constexpr float kCellSize = 30;  // W (:761)
+constexpr int kSelPad = 4;       // a level keeps at most quota+3 nodes; slots are quota+kSelPad
+
+// Geometry of one pyramid level for the current image size. Passed to kernels by value.
+struct LevelGeom {
+    int w, h;               // level size (:1104)
+    int stride;             // row pitch in bytes inside the pyramid buffer (levels >= 1)
+    long long offset;       // byte offset of the level inside one frame's pyramid buffer (levels >= 1)
+    int nCols, nRows;       // FAST cell grid (:776-777); 0 when the level is too small for one cell
+    int wCell, hCell;       // (:778-779)
+    int cellBase;           // first cell of this level in a frame's cell arrays
+    int slotCap;            // candidate capacity of one cell
+    long long slotBase;     // first slot entry of this level in a frame's slot / candidate arrays
+    int quota;              // mnFeaturesPerLevel[level]
+    int selBase;            // first entry of this level's selected-keypoint region (quota+kSelPad long)
+    int nIni;               // root nodes of the quadtree (:535)
+    float hX;               // root width (:537)
+    float scale;            // mvScaleFactor[level]
+    float kpSize;           // (float)(int)(31*scale) (:829)
+};
+
+struct PyramidGeom {
+    int nlevels;
+    int width, height;      // level-0 size
+    int totalCells;         // per frame
+    long long totalSlots;   // per frame
+    int totalSel;           // per frame
+    long long pyrBytes;     // per frame, levels >= 1
+    int nodeCap;            // quadtree node table capacity
+    int maxTileBytes;       // LDS bytes of the largest FAST cell tile
+    int maxScanPix;         // most scanned pixels in one cell
+    int maxScoreBytes;      // LDS bytes of the largest cell score map
+    LevelGeom lv[ORBX_MAX_LEVELS];
+};
+
+// Device pointers of one batched call. Passed to kernels by value.
+struct FrameSet {
+    const uint8_t* img;     // level 0: caller's frames
+    long long imgRowStride, imgFrameStride;
+    uint8_t* pyr;           // levels >= 1
+    int32_t* cellCount;     // [frame][totalCells]
+    uint32_t* slots;        // [frame][totalSlots] packed candidates, grouped per cell
+    uint32_t* cand;         // [frame][totalSlots] candidates of a level in reference order (spill space)
+    uint16_t* nid;          // [frame][totalSlots] quadtree node of each candidate (spill space)
+    uint32_t* sel;          // [frame][totalSel] packed selected keypoints
+    int32_t* selCount;      // [frame][nlevels]
+};
+
+// Bilinear resize tables of one level (cv::resize INTER_LINEAR, 8U fixed point).
+struct ResizeTab {
+    const int32_t* xofs;    // [dw]
+    const int16_t* ialpha;  // [dw][2]
+    const int32_t* yofs;    // [dh]
+    const int16_t* ibeta;   // [dh][2]
+    int xmax;
+};
+
+// candidate packing: x (12 bits) | y (12 bits) << 12 | score << 24; x, y relative to the 16-px border
+__host__ __device__ inline uint32_t pack_cand(int x, int y, int score) {
+    return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)score << 24);
+}
+__host__ __device__ inline int cand_x(uint32_t c) { return (int)(c & 0xFFFu); }
+__host__ __device__ inline int cand_y(uint32_t c) { return (int)((c >> 12) & 0xFFFu); }
+__host__ __device__ inline int cand_score(uint32_t c) { return (int)(c >> 24); }
+
+// ---- host-side tables (tables.cpp) ----
+struct ScaleTables {
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> perLevel;
+    int umax[kHalfPatch + 1];
+};
+void build_scale_tables(int nfeatures, float scaleFactor, int nlevels, ScaleTables& t);
+bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g, std::string& err);
+struct HostResizeTab {
+    std::vector<int32_t> xofs, yofs;
+    std::vector<int16_t> ialpha, ibeta;
+    int xmax;
+};
+void build_resize_table(int sw, int sh, int dw, int dh, HostResizeTab& t);
+
+// ---- error plumbing ----
+void set_error(const char* fmt, ...);
+
+// ---- kernel launchers (one per .hip file) ----
+hipError_t launch_pyramid(const FrameSet& fs, const PyramidGeom& g, const ResizeTab* tabs, int nframes,
+                          hipStream_t s);
+hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nframes, int iniTh, int minTh,
+                             hipStream_t s);
+hipError_t launch_octree(const FrameSet& fs, const PyramidGeom& g, int nframes, hipStream_t s);
+hipError_t launch_orient_desc(const FrameSet& fs, const PyramidGeom& g, int nframes, int blurTaps,
+                              orbx_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, hipStream_t s);
+hipError_t launch_blur_level(const uint8_t* src, int w, int h, long long stride, uint8_t* dst,
+                             long long dstStride, int blurTaps, hipStream_t s);
+size_t octree_lds_bytes(const PyramidGeom& g);
+
+hipError_t launch_knn2(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb, int32_t init,
+                       int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2, void* scratch,
+                       size_t scratchBytes, hipStream_t s);
+size_t knn2_scratch_bytes(int64_t nq, int64_t ndb);
+hipError_t launch_knn2_merge(int nparts, int64_t nq, const int64_t* idx, const int32_t* d1,
+                             const int32_t* d2, int32_t init, int64_t* oidx, int32_t* od1, int32_t* od2,
+                             hipStream_t s);
+hipError_t launch_ratio_test(int64_t nq, const int32_t* d1, const int32_t* d2, int32_t th, int inclusive,
+                             float ratio, uint8_t* accept, hipStream_t s);
+hipError_t launch_stereo_band(int npairs, int cap, const orbx_keypoint* kl, const uint8_t* dl,
+                              const int32_t* nl, const orbx_keypoint* kr, const uint8_t* dr,
+                              const int32_t* nr, const float* scale, int nlevels, float maxD,
+                              int32_t* bestIdx, int32_t* bestDist, hipStream_t s);
+
+}  // namespace orbx

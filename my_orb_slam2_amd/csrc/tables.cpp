@@ -1,0 +1,170 @@
+// Host-side tables: scale factors, per-level quotas, pyramid / cell-grid geometry and the
+// fixed-point coefficient tables of the bilinear resize. Shared by every frame of a batch, so the
+// coefficient rounding is done once, on the host, in the exact float arithmetic the reference uses.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+
+#include "orbx_internal.h"
+
+namespace orbx {
+
+namespace {
+thread_local char g_err[512] = "";
+
+inline int cv_round(double v) { return (int)std::nearbyint(v); }   // round half to even
+inline int cv_round(float v) { return (int)std::nearbyintf(v); }
+inline int16_t sat_short(float v) {
+    int i = cv_round(v);
+    return (int16_t)std::min(32767, std::max(-32768, i));
+}
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* orbx_last_error(void) { return g_err; }
+
+// ORBextractor::ORBextractor (src/ORBextractor.cc:402-462). scaleFactor is a double member there
+// (include/ORBextractor.h:113), so the cumulative product and 1/scaleFactor go through double.
+void build_scale_tables(int nfeatures, float scaleFactor, int nlevels, ScaleTables& t) {
+    const double sf = scaleFactor;
+    t.scale.assign(nlevels, 1.0f);
+    t.sigma2.assign(nlevels, 1.0f);
+    for (int i = 1; i < nlevels; i++) {
+        t.scale[i] = (float)(t.scale[i - 1] * sf);
+        t.sigma2[i] = t.scale[i] * t.scale[i];
+    }
+    t.invScale.resize(nlevels);
+    t.invSigma2.resize(nlevels);
+    for (int i = 0; i < nlevels; i++) {
+        t.invScale[i] = 1.0f / t.scale[i];
+        t.invSigma2[i] = 1.0f / t.sigma2[i];
+    }
+    t.perLevel.assign(nlevels, 0);
+    const float factor = (float)(1.0f / sf);
+    float want = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) {
+        t.perLevel[l] = cv_round(want);
+        sum += t.perLevel[l];
+        want *= factor;
+    }
+    t.perLevel[nlevels - 1] = std::max(nfeatures - sum, 0);
+
+    // end of each row of the radius-15 disc used by the intensity centroid (:446-461)
+    int um[kHalfPatch + 2] = {0};
+    const int vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    const int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = (double)kHalfPatch * kHalfPatch;
+    for (int v = 0; v <= vmax; ++v) um[v] = cv_round(std::sqrt(hp2 - v * v));
+    for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+        while (um[v0] == um[v0 + 1]) ++v0;
+        um[v] = v0;
+        ++v0;
+    }
+    for (int v = 0; v <= kHalfPatch; v++) t.umax[v] = um[v];
+}
+
+// Level sizes (src/ORBextractor.cc:1103-1104), FAST cell grid (:765-779) and quadtree roots
+// (:535-537) for one image size, plus where each level's data lives inside a frame's buffers.
+bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g, std::string& err) {
+    const int nlevels = (int)t.scale.size();
+    g = PyramidGeom();
+    g.nlevels = nlevels;
+    g.width = width;
+    g.height = height;
+    long long pyr = 0, slots = 0;
+    int cells = 0, sel = 0;
+    g.nodeCap = 16;
+    for (int l = 0; l < nlevels; l++) {
+        LevelGeom& L = g.lv[l];
+        L.w = cv_round((float)width * t.invScale[l]);
+        L.h = cv_round((float)height * t.invScale[l]);
+        if (L.w < 1 || L.h < 1) { L.w = 0; L.h = 0; }
+        L.stride = align_up(std::max(L.w, 1), 64);
+        L.offset = pyr;
+        if (l > 0) pyr += (long long)L.stride * L.h;
+        pyr = (pyr + 255) / 256 * 256;
+        L.quota = t.perLevel[l];
+        L.scale = t.scale[l];
+        L.kpSize = (float)(int)(kPatchSize * t.scale[l]);
+        const int minB = kBorder, maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+        const float fw = (float)(maxBX - minB), fh = (float)(maxBY - minB);
+        int nCols = maxBX > minB ? (int)(fw / kCellSize) : 0;
+        int nRows = maxBY > minB ? (int)(fh / kCellSize) : 0;
+        int nIni = 0;
+        if (nCols >= 1 && nRows >= 1) nIni = (int)std::round(fw / fh);
+        // The reference divides by zero when a level is narrower than one cell or much taller
+        // than wide; such levels produce no keypoints here.
+        if (nCols < 1 || nRows < 1 || nIni < 1) { nCols = nRows = nIni = 0; }
+        L.nCols = nCols;
+        L.nRows = nRows;
+        L.wCell = nCols ? (int)std::ceil(fw / nCols) : 0;
+        L.hCell = nRows ? (int)std::ceil(fh / nRows) : 0;
+        L.nIni = nIni;
+        L.hX = nIni ? fw / nIni : 0.f;
+        L.cellBase = cells;
+        L.slotCap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+        L.slotBase = slots;
+        L.selBase = sel;
+        cells += nCols * nRows;
+        slots += (long long)nCols * nRows * L.slotCap;
+        sel += L.quota + kSelPad;
+        g.nodeCap = std::max(g.nodeCap, std::max(L.quota + 8, 4 * nIni + 8));
+        if (nCols) {
+            const int ndw = (3 + L.wCell + 6 + 3) >> 2;
+            g.maxTileBytes = std::max(g.maxTileBytes, 4 * ndw * (L.hCell + 6));
+            g.maxScanPix = std::max(g.maxScanPix, L.wCell * L.hCell);
+            g.maxScoreBytes = std::max(g.maxScoreBytes, align_up((L.wCell + 2) * (L.hCell + 2), 4));
+        }
+        if (L.w > 4096 + 2 * kBorder || L.h > 4096 + 2 * kBorder) {
+            err = "image larger than 4096 px per side";
+            return false;
+        }
+    }
+    g.totalCells = cells;
+    g.totalSlots = slots;
+    g.totalSel = sel;
+    g.pyrBytes = std::max(pyr, 256LL);
+    return true;
+}
+
+// Coefficient tables of cv::resize(INTER_LINEAR) for CV_8U: offsets from
+// fx = (float)((dx+0.5)*scale - 0.5), weights rounded to 11-bit fixed point (cv: resize.cpp,
+// INTER_RESIZE_COEF_BITS = 11). Called for src/ORBextractor.cc:1112.
+void build_resize_table(int sw, int sh, int dw, int dh, HostResizeTab& t) {
+    t.xofs.assign(std::max(dw, 1), 0);
+    t.yofs.assign(std::max(dh, 1), 0);
+    t.ialpha.assign(2 * (size_t)std::max(dw, 1), 0);
+    t.ibeta.assign(2 * (size_t)std::max(dh, 1), 0);
+    t.xmax = dw;
+    if (sw < 1 || sh < 1 || dw < 1 || dh < 1) return;
+    const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)std::floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { t.xmax = std::min(t.xmax, dx); fx = 0; sx = sw - 1; }
+        t.xofs[dx] = sx;
+        t.ialpha[2 * dx] = sat_short((1.f - fx) * 2048);
+        t.ialpha[2 * dx + 1] = sat_short(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)std::floor(fy);
+        fy -= sy;
+        t.yofs[dy] = sy;
+        t.ibeta[2 * dy] = sat_short((1.f - fy) * 2048);
+        t.ibeta[2 * dy + 1] = sat_short(fy * 2048);
+    }
+}
+
+}  // namespace orbx

@@ -1,0 +1,100 @@
+"""Host mirror of the Hamming half of ORB_SLAM2::ORBmatcher (my_orb_slam2/include/ORBmatcher.h)
+and of the descriptor band search of Frame::ComputeStereoMatches (src/Frame.cc:503-586)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib, np_ptr
+
+# include/PresetParameters.h:11-13
+TH_HIGH = 100
+TH_LOW = 50
+HISTO_LENGTH = 30
+
+
+class ORBmatcher:
+    """Static distance + default ratio of the reference's matcher (include/ORBmatcher.h:44-47)."""
+
+    def __init__(self, nnratio=0.6, checkOri=True):
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1698-1714) on two 32-byte rows."""
+        a = np.ascontiguousarray(a, dtype=np.uint8).reshape(32)
+        b = np.ascontiguousarray(b, dtype=np.uint8).reshape(32)
+        return lib().orbx_hamming256(np_ptr(a), np_ptr(b))
+
+
+class HammingMatcher:
+    """Brute-force best / second-best search on the GPU (update rule of src/ORBmatcher.cc:204-229)."""
+
+    def __init__(self, device=0):
+        self._m = C.c_void_p()
+        check(lib().orbx_matcher_create(int(device), C.byref(self._m)), "orbx_matcher_create")
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_m", None) and self._m.value:
+            lib().orbx_matcher_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def knn2(self, query, db, init=256):
+        """Host arrays (nq, 32) and (ndb, 32) uint8 -> idx int64, d1, d2 int32."""
+        query = np.ascontiguousarray(query, dtype=np.uint8).reshape(-1, 32)
+        db = np.ascontiguousarray(db, dtype=np.uint8).reshape(-1, 32)
+        nq = query.shape[0]
+        idx = np.empty(nq, dtype=np.int64)
+        d1 = np.empty(nq, dtype=np.int32)
+        d2 = np.empty(nq, dtype=np.int32)
+        check(lib().orbx_hamming_knn2(self._m, np_ptr(query), nq, np_ptr(db), db.shape[0], int(init),
+                                      np_ptr(idx), np_ptr(d1), np_ptr(d2)), "orbx_hamming_knn2")
+        return idx, d1, d2
+
+    def knn2_device(self, d_query, d_db, d_idx, d_d1, d_d2, init=256, index_base=0, stream=None):
+        """torch CUDA tensors: (nq, 32) / (ndb, 32) uint8 in, int64 / int32 / int32 (nq,) out."""
+        sp = C.c_void_p(stream) if stream else None
+        check(lib().orbx_hamming_knn2_device(self._m, C.c_void_p(d_query.data_ptr()), d_query.shape[0],
+                                             C.c_void_p(d_db.data_ptr()), d_db.shape[0], int(init),
+                                             int(index_base), C.c_void_p(d_idx.data_ptr()),
+                                             C.c_void_p(d_d1.data_ptr()), C.c_void_p(d_d2.data_ptr()), sp),
+              "orbx_hamming_knn2_device")
+
+    def merge_device(self, d_idx, d_d1, d_d2, o_idx, o_d1, o_d2, init=256, stream=None):
+        """Merge (nparts, nq) partial results of consecutive database shards."""
+        nparts, nq = d_idx.shape
+        sp = C.c_void_p(stream) if stream else None
+        check(lib().orbx_knn2_merge_device(self._m, nparts, nq, C.c_void_p(d_idx.data_ptr()),
+                                           C.c_void_p(d_d1.data_ptr()), C.c_void_p(d_d2.data_ptr()), int(init),
+                                           C.c_void_p(o_idx.data_ptr()), C.c_void_p(o_d1.data_ptr()),
+                                           C.c_void_p(o_d2.data_ptr()), sp), "orbx_knn2_merge_device")
+
+    def ratio_test_device(self, d_d1, d_d2, d_accept, th=TH_LOW, inclusive=True, ratio=0.6, stream=None):
+        sp = C.c_void_p(stream) if stream else None
+        check(lib().orbx_ratio_test_device(self._m, d_d1.shape[0], C.c_void_p(d_d1.data_ptr()),
+                                           C.c_void_p(d_d2.data_ptr()), int(th), 1 if inclusive else 0,
+                                           float(ratio), C.c_void_p(d_accept.data_ptr()), sp),
+              "orbx_ratio_test_device")
+
+    def stereo_band_match_device(self, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, scale_factors, bf, b,
+                                 d_best_idx, d_best_dist, stream=None):
+        """Descriptor band search for (npairs, cap, ...) left/right keypoint sets on the device."""
+        npairs, cap = d_dl.shape[0], d_dl.shape[1]
+        sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+        sp = C.c_void_p(stream) if stream else None
+        check(lib().orbx_stereo_band_match_device(
+            self._m, npairs, cap, C.c_void_p(d_kl.data_ptr()), C.c_void_p(d_dl.data_ptr()),
+            C.c_void_p(d_nl.data_ptr()), C.c_void_p(d_kr.data_ptr()), C.c_void_p(d_dr.data_ptr()),
+            C.c_void_p(d_nr.data_ptr()), np_ptr(sf), sf.shape[0], float(bf), float(b),
+            C.c_void_p(d_best_idx.data_ptr()), C.c_void_p(d_best_dist.data_ptr()), sp),
+            "orbx_stereo_band_match_device")
+
+    def synchronize(self):
+        check(lib().orbx_matcher_synchronize(self._m), "orbx_matcher_synchronize")

@@ -1,0 +1,106 @@
+/*
+ * orb_oracle.h — CPU restatement of the ORB front end of One-sixth/my_orb_slam2.
+ *
+ * THIS IS TEST INFRASTRUCTURE.  Nothing under oracle/ is part of the shipped
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library, and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference holds no tests, fixtures or golden vectors for
+ * this path and it cannot be compiled here (it needs OpenCV 4.0.0, DBoW3, g2o).
+ * The arithmetic that matters lives in OpenCV 4.0.0 (cv::resize, cv::FAST,
+ * cv::GaussianBlur, cv::fastAtan2, cvRound), which is not vendored under
+ * /root/reference; it is restated here from its published algorithm and pinned
+ * only by analytic known-answer tests (tests/test_oracle_kat.py).
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * /root/reference/my_orb_slam2/).
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same layout as cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id. */
+typedef struct orc_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+
+enum { ORC_BLUR_CV_4_0_0 = 0, ORC_BLUR_CV_4_2_PLUS = 1 };
+
+/* ---- primitives (OpenCV 4.0.0 semantics) -------------------------------- */
+int   orc_cv_round_f(float v);                       /* cvRound: round half to even */
+float orc_fast_atan2(float y, float x);              /* cv::fastAtan2, degrees [0,360) */
+void  orc_resize_linear_u8(const uint8_t* src, int sw, int sh, long sstride,
+                           uint8_t* dst, int dw, int dh, long dstride);
+void  orc_gaussian7_u8(const uint8_t* src, int w, int h, long sstride,
+                       uint8_t* dst, long dstride, int variant);
+/* cv::FAST(img, kps, threshold, nonmaxSuppression) with TYPE_9_16. Returns the number found
+ * (may exceed cap; only the first cap are stored). */
+int   orc_fast9_16(const uint8_t* img, int w, int h, long stride, int threshold, int nms,
+                   orc_keypoint* out, int cap);
+/* DistributeOctTree (src/ORBextractor.cc:531-755). Coordinates are relative to (minX,minY).
+ * Returns the number selected, written in list order. */
+int   orc_distribute_octree(const orc_keypoint* in, int n, int minX, int maxX, int minY, int maxY,
+                            int N, orc_keypoint* out, int cap);
+
+/* ---- extractor (src/ORBextractor.cc) ------------------------------------ */
+typedef struct orc_extractor orc_extractor;
+orc_extractor* orc_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+                          int minThFAST, int blur_variant);
+void  orc_destroy(orc_extractor* e);
+/* ORBextractor::operator() (:1035-1097). Returns the number of keypoints (<= cap stored),
+ * or -1 on bad arguments. An empty image returns 0 and leaves outputs untouched. */
+int   orc_extract(orc_extractor* e, const uint8_t* img, int w, int h, long stride,
+                  orc_keypoint* kps, uint8_t* desc, int cap);
+/* Same, without keeping stage dumps (used for timing). */
+int   orc_extract_fast(orc_extractor* e, const uint8_t* img, int w, int h, long stride,
+                       orc_keypoint* kps, uint8_t* desc, int cap);
+
+/* tables (ORBextractor.cc:402-462) */
+int   orc_levels(const orc_extractor* e);
+void  orc_scale_factors(const orc_extractor* e, float* scale, float* inv_scale,
+                        float* sigma2, float* inv_sigma2);
+void  orc_features_per_level(const orc_extractor* e, int* out);
+void  orc_umax(const orc_extractor* e, int* out16);
+
+/* stage dumps of the last orc_extract() call */
+int   orc_level_size(const orc_extractor* e, int level, int* w, int* h);
+/* Copies the level with its 19-px BORDER_REFLECT_101 frame: (w+38) x (h+38). */
+int   orc_level_padded(const orc_extractor* e, int level, uint8_t* dst, long dstride);
+int   orc_level_image(const orc_extractor* e, int level, uint8_t* dst, long dstride);
+int   orc_level_blurred(const orc_extractor* e, int level, uint8_t* dst, long dstride);
+/* vToDistributeKeys of a level (:770-821): coordinates relative to the 16-px border. */
+int   orc_level_candidates(const orc_extractor* e, int level, orc_keypoint* out, int cap);
+/* keypoints of a level after DistributeOctTree + border + orientation (:823-844), level coords. */
+int   orc_level_selected(const orc_extractor* e, int level, orc_keypoint* out, int cap);
+
+/* ---- matcher ------------------------------------------------------------- */
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1698-1714), SWAR popcount. */
+int   orc_hamming256(const uint8_t* a, const uint8_t* b);
+int   orc_hamming256_popcnt(const uint8_t* a, const uint8_t* b);
+/* best / second-best scan of src/ORBmatcher.cc:204-229: for each query the full database is
+ * scanned in index order; d1,d2 start at `init` (256 there), idx at -1. use_popcnt selects the
+ * distance routine (same results). */
+void  orc_knn2(const uint8_t* q, long nq, const uint8_t* db, long ndb, int init, int use_popcnt,
+               int32_t* idx, int32_t* d1, int32_t* d2);
+/* acceptance test of :231-233 / :467-469 (inclusive!=0) and :619-621 (inclusive==0) */
+int   orc_ratio_accept(int d1, int d2, int th, int inclusive, float ratio);
+/* Frame::ComputeStereoMatches band search (src/Frame.cc:503-586): per left keypoint the best
+ * right index and distance; best_dist = TH_HIGH (100) and best_idx = -1 when nothing beat it
+ * (the reference leaves bestIdxR = 0 there; it is never used since 100 >= thOrbDist).
+ * rows = image rows of level 0, scale = mvScaleFactors. Returns 0, or -1 if a row index falls
+ * outside [0,rows) (the reference would write out of bounds). */
+int   orc_stereo_band_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
+                            const orc_keypoint* kr, const uint8_t* dr, int nr,
+                            int rows, const float* scale, int nlevels, float bf, float b,
+                            int32_t* best_idx, int32_t* best_dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

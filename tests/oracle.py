@@ -1,0 +1,207 @@
+"""ctypes binding of oracle/liborb_oracle.so — the CPU restatement used ONLY as the checker."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KP = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+               ("octave", "<i4"), ("class_id", "<i4")])
+BLUR_CV_4_0_0, BLUR_CV_4_2_PLUS = 0, 1
+_LIB = None
+_P = C.c_void_p
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "liborb_oracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        L = C.CDLL(path)
+        L.orc_cv_round_f.restype = C.c_int
+        L.orc_cv_round_f.argtypes = [C.c_float]
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_resize_linear_u8.restype = None
+        L.orc_resize_linear_u8.argtypes = [_P, C.c_int, C.c_int, C.c_long, _P, C.c_int, C.c_int, C.c_long]
+        L.orc_gaussian7_u8.restype = None
+        L.orc_gaussian7_u8.argtypes = [_P, C.c_int, C.c_int, C.c_long, _P, C.c_long, C.c_int]
+        L.orc_fast9_16.restype = C.c_int
+        L.orc_fast9_16.argtypes = [_P, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, _P, C.c_int]
+        L.orc_distribute_octree.restype = C.c_int
+        L.orc_distribute_octree.argtypes = [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int]
+        L.orc_create.restype = _P
+        L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_destroy.restype = None
+        L.orc_destroy.argtypes = [_P]
+        for name in ("orc_extract", "orc_extract_fast"):
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = [_P, _P, C.c_int, C.c_int, C.c_long, _P, _P, C.c_int]
+        L.orc_levels.restype = C.c_int
+        L.orc_levels.argtypes = [_P]
+        L.orc_scale_factors.restype = None
+        L.orc_scale_factors.argtypes = [_P, _P, _P, _P, _P]
+        L.orc_features_per_level.restype = None
+        L.orc_features_per_level.argtypes = [_P, _P]
+        L.orc_umax.restype = None
+        L.orc_umax.argtypes = [_P, _P]
+        L.orc_level_size.restype = C.c_int
+        L.orc_level_size.argtypes = [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        for name in ("orc_level_padded", "orc_level_image", "orc_level_blurred"):
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = [_P, C.c_int, _P, C.c_long]
+        for name in ("orc_level_candidates", "orc_level_selected"):
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = [_P, C.c_int, _P, C.c_int]
+        for name in ("orc_hamming256", "orc_hamming256_popcnt"):
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = [_P, _P]
+        L.orc_knn2.restype = None
+        L.orc_knn2.argtypes = [_P, C.c_long, _P, C.c_long, C.c_int, C.c_int, _P, _P, _P]
+        L.orc_ratio_accept.restype = C.c_int
+        L.orc_ratio_accept.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+        L.orc_stereo_band_match.restype = C.c_int
+        L.orc_stereo_band_match.argtypes = [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, C.c_int,
+                                            C.c_float, C.c_float, _P, _P]
+        _LIB = L
+    return _LIB
+
+
+def ptr(a):
+    return a.ctypes.data_as(_P)
+
+
+def resize(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.empty((dh, dw), dtype=np.uint8)
+    lib().orc_resize_linear_u8(ptr(src), src.shape[1], src.shape[0], src.strides[0], ptr(dst), dw, dh, dst.strides[0])
+    return dst
+
+
+def gaussian7(src, variant=BLUR_CV_4_0_0):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.empty_like(src)
+    lib().orc_gaussian7_u8(ptr(src), src.shape[1], src.shape[0], src.strides[0], ptr(dst), dst.strides[0], variant)
+    return dst
+
+
+def fast(img, threshold, nms=True, cap=200000):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty(cap, dtype=KP)
+    n = lib().orc_fast9_16(ptr(img), img.shape[1], img.shape[0], img.strides[0], threshold, 1 if nms else 0, ptr(out), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def distribute_octree(kps, minX, maxX, minY, maxY, N):
+    kps = np.ascontiguousarray(kps, dtype=KP)
+    out = np.empty(max(len(kps), 1), dtype=KP)
+    n = lib().orc_distribute_octree(ptr(kps), len(kps), minX, maxX, minY, maxY, N, ptr(out), len(out))
+    return out[:n].copy()
+
+
+class Extractor:
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini=20, mn=7, blur=BLUR_CV_4_0_0):
+        self.h = lib().orc_create(nfeatures, scale, nlevels, ini, mn, blur)
+        assert self.h
+        self.nlevels = nlevels
+        self.cap = nfeatures + 4 * nlevels + 64
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_destroy(self.h)
+            self.h = None
+
+    def extract(self, img, fast=False):
+        kps = np.empty(self.cap, dtype=KP)
+        desc = np.zeros((self.cap, 32), dtype=np.uint8)
+        if img is None or img.size == 0:
+            n = lib().orc_extract(self.h, None, 0, 0, 0, ptr(kps), ptr(desc), self.cap)
+            return kps[:n], desc[:n]
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        fn = lib().orc_extract_fast if fast else lib().orc_extract
+        n = fn(self.h, ptr(img), img.shape[1], img.shape[0], img.strides[0], ptr(kps), ptr(desc), self.cap)
+        assert 0 <= n <= self.cap
+        return kps[:n].copy(), desc[:n].copy()
+
+    def scale_factors(self):
+        out = [np.empty(self.nlevels, dtype=np.float32) for _ in range(4)]
+        lib().orc_scale_factors(self.h, *[ptr(o) for o in out])
+        return out
+
+    def features_per_level(self):
+        out = np.empty(self.nlevels, dtype=np.int32)
+        lib().orc_features_per_level(self.h, ptr(out))
+        return out
+
+    def umax(self):
+        out = np.empty(16, dtype=np.int32)
+        lib().orc_umax(self.h, ptr(out))
+        return out
+
+    def level_size(self, level):
+        w, h = C.c_int(0), C.c_int(0)
+        assert lib().orc_level_size(self.h, level, C.byref(w), C.byref(h)) == 0
+        return w.value, h.value
+
+    def level_image(self, level, padded=False):
+        w, h = self.level_size(level)
+        pad = 38 if padded else 0
+        out = np.empty((h + pad, w + pad), dtype=np.uint8)
+        fn = lib().orc_level_padded if padded else lib().orc_level_image
+        assert fn(self.h, level, ptr(out), out.strides[0]) == 0
+        return out
+
+    def level_blurred(self, level):
+        w, h = self.level_size(level)
+        out = np.empty((h, w), dtype=np.uint8)
+        rc = lib().orc_level_blurred(self.h, level, ptr(out), out.strides[0])
+        return out if rc == 0 else None
+
+    def _list(self, fn, level):
+        out = np.empty(400000, dtype=KP)
+        n = fn(self.h, level, ptr(out), len(out))
+        assert 0 <= n <= len(out)
+        return out[:n].copy()
+
+    def level_candidates(self, level):
+        return self._list(lib().orc_level_candidates, level)
+
+    def level_selected(self, level):
+        return self._list(lib().orc_level_selected, level)
+
+
+def hamming(a, b, popcnt=False):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return (lib().orc_hamming256_popcnt if popcnt else lib().orc_hamming256)(ptr(a), ptr(b))
+
+
+def knn2(q, db, init=256, popcnt=True):
+    q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 32)
+    db = np.ascontiguousarray(db, dtype=np.uint8).reshape(-1, 32)
+    idx = np.empty(len(q), dtype=np.int32)
+    d1 = np.empty(len(q), dtype=np.int32)
+    d2 = np.empty(len(q), dtype=np.int32)
+    lib().orc_knn2(ptr(q), len(q), ptr(db), len(db), init, 1 if popcnt else 0, ptr(idx), ptr(d1), ptr(d2))
+    return idx, d1, d2
+
+
+def stereo_band_match(kl, dl, kr, dr, rows, scale, bf, b):
+    kl = np.ascontiguousarray(kl, dtype=KP)
+    kr = np.ascontiguousarray(kr, dtype=KP)
+    dl = np.ascontiguousarray(dl, dtype=np.uint8)
+    dr = np.ascontiguousarray(dr, dtype=np.uint8)
+    scale = np.ascontiguousarray(scale, dtype=np.float32)
+    bi = np.empty(len(kl), dtype=np.int32)
+    bd = np.empty(len(kl), dtype=np.int32)
+    rc = lib().orc_stereo_band_match(ptr(kl), ptr(dl), len(kl), ptr(kr), ptr(dr), len(kr), rows, ptr(scale),
+                                     len(scale), bf, b, ptr(bi), ptr(bd))
+    assert rc == 0
+    return bi, bd

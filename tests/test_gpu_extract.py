@@ -1,0 +1,188 @@
+"""GPU parity tests: the HIP extractor (through the C ABI) against the CPU oracle, stage by stage.
+
+Bars: pyramid, blur, FAST candidate list and quadtree selection bit-exact (same values, same order);
+angles within 1e-3 degree; descriptors bit-exact (per-bit mismatch rate reported, must be 0)."""
+import numpy as np
+import pytest
+
+import my_orb_slam2_amd as m
+from my_orb_slam2_amd import synth
+from tests import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ANGLE_TOL_DEG = 1e-3
+
+
+def make(nfeatures=1000, w=752, h=480, batch=1, blur=m.BLUR_CV_4_0_0, nlevels=8, scale=1.2, ini=20, mn=7):
+    gpu = m.ORBextractor(nfeatures, scale, nlevels, ini, mn, max_width=w, max_height=h, max_batch=batch,
+                         blur_taps=blur)
+    cpu = orc.Extractor(nfeatures, scale, nlevels, ini, mn, blur)
+    return gpu, cpu
+
+
+def compare_frame(gpu, cpu, img, frame_kps=None, frame_desc=None, stages=True):
+    ck, cd = cpu.extract(img)
+    if frame_kps is None:
+        gk, gd = gpu(img)
+    else:
+        gk, gd = frame_kps, frame_desc
+    if stages:
+        for l in range(cpu.nlevels):
+            assert gpu.level_size(l) == cpu.level_size(l)
+            w, h = cpu.level_size(l)
+            if w == 0:
+                continue
+            assert np.array_equal(gpu.get_level(l), cpu.level_image(l)), "pyramid level %d" % l
+            cc = cpu.level_candidates(l)
+            gc = gpu.debug_candidates(l)
+            assert len(gc) == len(cc), "candidate count level %d: %d vs %d" % (l, len(gc), len(cc))
+            for f in ("x", "y", "response"):
+                assert np.array_equal(gc[f], cc[f]), "candidates level %d field %s" % (l, f)
+            cs = cpu.level_selected(l)
+            gs = gpu.debug_selected(l)
+            assert len(gs) == len(cs), "selected count level %d: %d vs %d" % (l, len(gs), len(cs))
+            for f in ("x", "y", "response", "octave", "size"):
+                assert np.array_equal(gs[f], cs[f]), "selected level %d field %s" % (l, f)
+            cb = cpu.level_blurred(l)
+            if cb is not None:
+                assert np.array_equal(gpu.debug_blur_level(l), cb), "blur level %d" % l
+    assert len(gk) == len(ck)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(gk[f], ck[f]), f
+    if len(ck):
+        da = np.abs(gk["angle"] - ck["angle"])
+        da = np.minimum(da, 360 - da)
+        assert da.max() <= ANGLE_TOL_DEG, "angle error %g deg" % da.max()
+        bits = np.unpackbits(gd ^ cd).sum()
+        rate = bits / float(cd.size * 8)
+        assert rate == 0, "descriptor per-bit mismatch rate %g" % rate
+    return len(ck)
+
+
+def test_scene_frames_all_stages():
+    gpu, cpu = make()
+    total = 0
+    for i in range(4):
+        total += compare_frame(gpu, cpu, m.synth_frame(i))
+    assert total > 3500
+
+
+def test_degenerate_frames():
+    gpu, cpu = make()
+    for kind in (synth.ZERO, synth.CONST128):
+        assert compare_frame(gpu, cpu, m.synth_frame(1, kind=kind)) == 0
+    # pure noise: ~33k candidates at level 0, exercises the quadtree's global-memory spill path
+    assert compare_frame(gpu, cpu, m.synth_frame(2, kind=synth.NOISE)) > 900
+
+
+def test_blur_variant_4_2():
+    gpu, cpu = make(blur=m.BLUR_CV_4_2_PLUS)
+    compare_frame(gpu, cpu, m.synth_frame(7))
+
+
+def test_getters_match_reference_tables():
+    gpu, cpu = make()
+    s, inv, sg, isg = cpu.scale_factors()
+    assert gpu.GetLevels() == 8 and gpu.GetScaleFactor() == np.float32(1.2)
+    assert np.array_equal(gpu.GetScaleFactors(), s)
+    assert np.array_equal(gpu.GetInverseScaleFactors(), inv)
+    assert np.array_equal(gpu.GetScaleSigmaSquares(), sg)
+    assert np.array_equal(gpu.GetInverseScaleSigmaSquares(), isg)
+    assert np.array_equal(gpu.features_per_level(), cpu.features_per_level())
+    assert np.array_equal(gpu.umax(), cpu.umax())
+
+
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (321, 243, 500), (1241, 376, 2000), (1920, 1080, 2000),
+                                    (97, 80, 300)])
+def test_other_sizes(w, h, nf):
+    gpu, cpu = make(nfeatures=nf, w=w, h=h)
+    compare_frame(gpu, cpu, m.synth_frame(11, w, h))
+
+
+def test_other_parameters():
+    gpu, cpu = make(nfeatures=1200, nlevels=5, scale=1.5, ini=30, mn=10)
+    compare_frame(gpu, cpu, m.synth_frame(3))
+    gpu, cpu = make(nfeatures=300, nlevels=1, ini=12, mn=12)
+    compare_frame(gpu, cpu, m.synth_frame(4))
+
+
+def test_unaligned_rows_and_smaller_image_in_big_context():
+    gpu, cpu = make(w=800, h=600)
+    big = np.zeros((480, 757), np.uint8)
+    img = m.synth_frame(5, 751, 479)
+    big[1:, 5:756] = img
+    view = big[1:, 5:756]            # odd base address, odd pitch
+    ck, cd = cpu.extract(np.ascontiguousarray(view))
+    gk, gd = gpu(view)
+    assert np.array_equal(gk["x"], ck["x"]) and np.array_equal(gd, cd)
+    compare_frame(gpu, cpu, np.ascontiguousarray(view))
+
+
+def test_batch_equals_single_and_device_api():
+    import torch
+    B = 6
+    gpu, cpu = make(batch=B)
+    frames = m.synth_batch(20, B)
+    frames[3] = 0                    # an empty frame inside the batch
+    res = gpu.extract_batch(frames)
+    for i in range(B):
+        ck, cd = cpu.extract(frames[i])
+        assert len(res[i][0]) == len(ck)
+        assert np.array_equal(res[i][0]["x"], ck["x"]) and np.array_equal(res[i][1], cd)
+    # device-resident API on torch tensors
+    cap = gpu.capacity
+    d_img = torch.from_numpy(frames).cuda()
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    gpu.extract_batch_device(d_img, d_kps, d_desc, d_cnt)
+    gpu.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28).copy().view(m.KEYPOINT_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy()
+    for i in range(B):
+        assert cnt[i] == len(res[i][0])
+        assert np.array_equal(kps[i, :cnt[i]], res[i][0])
+        assert np.array_equal(desc[i, :cnt[i]], res[i][1])
+    # probes address any frame of the batch
+    for i in (0, 5):
+        cpu.extract(frames[i])
+        assert np.array_equal(gpu.get_level(2, frame=i), cpu.level_image(2))
+        assert np.array_equal(gpu.get_level(1, frame=i, border=True), cpu.level_image(1, padded=True))
+
+
+def test_api_errors_and_empty_image():
+    gpu, _ = make()
+    k, d = gpu(np.empty((0, 0), np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    with pytest.raises(TypeError):
+        gpu(np.zeros((10, 10), np.float32))
+    with pytest.raises(m.OrbxError):
+        gpu(np.zeros((1000, 1000), np.uint8))             # larger than the context
+    import ctypes as C
+    from my_orb_slam2_amd._lib import lib, np_ptr
+    img = m.synth_frame(0)
+    kps = np.empty(10, m.KEYPOINT_DTYPE)
+    desc = np.empty((10, 32), np.uint8)
+    n = C.c_int(0)
+    rc = lib().orbx_extract(gpu._ctx, np_ptr(img), 752, 480, 752, np_ptr(kps), np_ptr(desc), 10, C.byref(n))
+    assert rc == -3 and n.value > 900                      # ORBX_ERR_CAPACITY, count reported
+    with pytest.raises(m.OrbxError):
+        m.ORBextractor(1000, 1.2, 99, 20, 7)
+    with pytest.raises(m.OrbxError):
+        m.ORBextractor(1000, 1.0, 8, 20, 7)
+
+
+def test_two_contexts_like_stereo():
+    left, cpu = make(nfeatures=1200)
+    right, _ = make(nfeatures=1200)
+    fl = m.synth_frame(30)
+    fr = m.synth_frame(30, right_view=True)
+    kl, dl = left(fl)
+    kr, dr = right(fr)
+    ckl, cdl = cpu.extract(fl)
+    ckr, cdr = cpu.extract(fr)
+    assert np.array_equal(dl, cdl) and np.array_equal(dr, cdr)
+    assert np.array_equal(kl["x"], ckl["x"]) and np.array_equal(kr["y"], ckr["y"])

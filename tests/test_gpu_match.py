@@ -1,0 +1,120 @@
+"""GPU parity tests for the Hamming matcher: match lists must be bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+import my_orb_slam2_amd as m
+from tests import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def planted(rng, nq, ndb):
+    db = rng.integers(0, 256, (ndb, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    half = nq // 2
+    src = rng.integers(0, ndb, half)
+    q[:half] = db[src]
+    for i in range(half):                          # flip r in [0, 40] random bits
+        for b in rng.integers(0, 256, rng.integers(0, 41)):
+            q[i, b // 8] ^= np.uint8(1 << (b % 8))
+    return q, db
+
+
+@pytest.mark.parametrize("nq,ndb", [(1, 1), (7, 0), (5, 1), (300, 1000), (1000, 5000), (513, 40000), (64, 300000)])
+def test_knn2_matches_oracle(nq, ndb):
+    rng = np.random.default_rng(nq * 7919 + ndb)
+    q, db = planted(rng, nq, max(ndb, 1))
+    db = db[:ndb]
+    hm = m.HammingMatcher()
+    for init in (256, 2**31 - 1):
+        idx, d1, d2 = hm.knn2(q, db, init=init)
+        oi, o1, o2 = orc.knn2(q, db, init=init)
+        assert np.array_equal(idx, oi) and np.array_equal(d1, o1) and np.array_equal(d2, o2)
+
+
+def test_knn2_ties_and_duplicates():
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+    db = np.concatenate([base, base, base[::-1]])          # every row appears three times
+    q = base.copy()
+    q[::2, 0] ^= 1
+    hm = m.HammingMatcher()
+    idx, d1, d2 = hm.knn2(q, db)
+    oi, o1, o2 = orc.knn2(q, db)
+    assert np.array_equal(idx, oi) and np.array_equal(d1, o1) and np.array_equal(d2, o2)
+    assert np.array_equal(d1, d2)                          # a tie with the best sets second = best
+    assert np.all(idx < 50)                                # lowest index wins
+
+
+def test_scalar_distance():
+    rng = np.random.default_rng(10)
+    for _ in range(50):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert m.ORBmatcher.DescriptorDistance(a, b) == orc.hamming(a, b)
+
+
+def test_sharded_merge_and_ratio_test():
+    import torch
+    rng = np.random.default_rng(11)
+    nq, ndb, shards = 2000, 30000, 4
+    q, db = planted(rng, nq, ndb)
+    hm = m.HammingMatcher()
+    dq = torch.from_numpy(q).cuda()
+    part_idx = torch.empty((shards, nq), dtype=torch.int64, device="cuda")
+    part_d1 = torch.empty((shards, nq), dtype=torch.int32, device="cuda")
+    part_d2 = torch.empty((shards, nq), dtype=torch.int32, device="cuda")
+    bounds = np.linspace(0, ndb, shards + 1).astype(int)
+    keep = []
+    for s in range(shards):
+        ddb = torch.from_numpy(db[bounds[s]:bounds[s + 1]]).cuda()
+        keep.append(ddb)
+        hm.knn2_device(dq, ddb, part_idx[s], part_d1[s], part_d2[s], index_base=int(bounds[s]))
+    o_idx = torch.empty(nq, dtype=torch.int64, device="cuda")
+    o_d1 = torch.empty(nq, dtype=torch.int32, device="cuda")
+    o_d2 = torch.empty(nq, dtype=torch.int32, device="cuda")
+    hm.merge_device(part_idx, part_d1, part_d2, o_idx, o_d1, o_d2)
+    acc = torch.empty(nq, dtype=torch.uint8, device="cuda")
+    hm.ratio_test_device(o_d1, o_d2, acc, th=m.TH_LOW, inclusive=True, ratio=0.6)
+    hm.synchronize()
+    oi, o1, o2 = orc.knn2(q, db)
+    assert np.array_equal(o_idx.cpu().numpy(), oi)
+    assert np.array_equal(o_d1.cpu().numpy(), o1) and np.array_equal(o_d2.cpu().numpy(), o2)
+    want = np.array([orc.lib().orc_ratio_accept(int(a), int(b), 50, 1, 0.6) for a, b in zip(o1, o2)], np.uint8)
+    assert np.array_equal(acc.cpu().numpy(), want)
+    assert 0.3 < want.mean() < 0.6                          # planted half passes, random half fails
+
+
+def test_stereo_band_match_on_extracted_pairs():
+    import torch
+    npairs = 3
+    ex_l = m.ORBextractor(1200, 1.2, 8, 20, 7)
+    ex_r = m.ORBextractor(1200, 1.2, 8, 20, 7)
+    cap = ex_l.capacity
+    kl = np.zeros((npairs, cap), m.KEYPOINT_DTYPE)
+    kr = np.zeros((npairs, cap), m.KEYPOINT_DTYPE)
+    dl = np.zeros((npairs, cap, 32), np.uint8)
+    dr = np.zeros((npairs, cap, 32), np.uint8)
+    nl = np.zeros(npairs, np.int32)
+    nr = np.zeros(npairs, np.int32)
+    for p in range(npairs):
+        a, b = ex_l(m.synth_frame(40 + p))
+        c, d = ex_r(m.synth_frame(40 + p, right_view=True))
+        nl[p], nr[p] = len(a), len(c)
+        kl[p, :len(a)], dl[p, :len(a)] = a, b
+        kr[p, :len(c)], dr[p, :len(c)] = c, d
+    scale = ex_l.GetScaleFactors()
+    bf, b = 47.90639384423901, 47.90639384423901 / 435.2046959714599    # EuRoC stereo: Camera.bf, bf / fx
+    hm = m.HammingMatcher()
+    t = lambda a: torch.from_numpy(a.view(np.uint8) if a.dtype == m.KEYPOINT_DTYPE else a).cuda()
+    best_idx = torch.empty((npairs, cap), dtype=torch.int32, device="cuda")
+    best_dist = torch.empty((npairs, cap), dtype=torch.int32, device="cuda")
+    hm.stereo_band_match_device(t(kl), t(dl), t(nl), t(kr), t(dr), t(nr), scale, bf, b, best_idx, best_dist)
+    hm.synchronize()
+    bi, bd = best_idx.cpu().numpy(), best_dist.cpu().numpy()
+    matched = 0
+    for p in range(npairs):
+        oi, od = orc.stereo_band_match(kl[p, :nl[p]], dl[p, :nl[p]], kr[p, :nr[p]], dr[p, :nr[p]], 480, scale, bf, b)
+        assert np.array_equal(bi[p, :nl[p]], oi) and np.array_equal(bd[p, :nl[p]], od)
+        matched += int((od < 75).sum())
+    assert matched > 300

@@ -1,0 +1,293 @@
+"""CPU tests: the oracle against analytic known answers and against independent numpy
+restatements.  The reference ships no golden vectors (parity unpinned), so these are the pins."""
+import numpy as np
+import pytest
+
+from tests import oracle as orc
+
+
+# ---------------------------------------------------------------- Hamming
+def test_hamming_known_answers():
+    z = np.zeros(32, np.uint8)
+    f = np.full(32, 255, np.uint8)
+    assert orc.hamming(z, z) == 0
+    assert orc.hamming(z, f) == 256
+    for bit in range(256):
+        a = z.copy()
+        a[bit // 8] = 1 << (bit % 8)
+        assert orc.hamming(a, z) == 1
+        assert orc.hamming(a, z, popcnt=True) == 1
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        want = int(np.unpackbits(a ^ b).sum())
+        assert orc.hamming(a, b) == want == orc.hamming(a, b, popcnt=True)
+
+
+def test_knn2_tie_rules():
+    # strict '<': lowest index wins a tie for best; a tie with best sets second = best
+    q = np.zeros((1, 32), np.uint8)
+    db = np.zeros((4, 32), np.uint8)
+    db[0, 0] = 0b111      # 3
+    db[1, 0] = 0b1        # 1
+    db[2, 0] = 0b10       # 1 (tie, later)
+    db[3, 0] = 0b11       # 2
+    idx, d1, d2 = orc.knn2(q, db)
+    assert (idx[0], d1[0], d2[0]) == (1, 1, 1)
+    idx, d1, d2 = orc.knn2(q, db[:1])
+    assert (idx[0], d1[0], d2[0]) == (0, 3, 256)
+    idx, d1, d2 = orc.knn2(q, db[:0])
+    assert (idx[0], d1[0], d2[0]) == (-1, 256, 256)
+    assert orc.lib().orc_ratio_accept(50, 100, 50, 1, 0.6) == 1
+    assert orc.lib().orc_ratio_accept(50, 100, 50, 0, 0.6) == 0
+    # float compare: 0.6f*50.f rounds to 30.000002, so 30 passes (it would fail in exact arithmetic)
+    assert orc.lib().orc_ratio_accept(30, 50, 50, 1, 0.6) == 1
+    assert orc.lib().orc_ratio_accept(31, 50, 50, 1, 0.6) == 0
+
+
+def test_ratio_float_compare():
+    # (float)30 < 0.6f*50.f : 0.6f = 0.60000002384, product rounds to 30.000002 -> accepted
+    assert np.float32(30) < np.float32(0.6) * np.float32(50)
+
+
+# ---------------------------------------------------------------- rounding / atan
+def test_cv_round_half_even():
+    for v, want in [(0.5, 0), (1.5, 2), (2.5, 2), (-0.5, 0), (-1.5, -2), (2.4999, 2), (2.5001, 3)]:
+        assert orc.lib().orc_cv_round_f(v) == want
+
+
+def test_fast_atan2_known_answers():
+    f = orc.lib().orc_fast_atan2
+    assert f(0, 1) == 0
+    assert f(1, 0) == 90
+    assert f(0, -1) == 180
+    assert f(-1, 0) == 270
+    assert f(0, 0) == 0
+    k = np.float32(180.0 / np.pi)
+    p = [np.float32(c) * k for c in (0.9997878412794807, -0.3258083974640975, 0.1555786518463281,
+                                     -0.04432655554792128)]
+    c = np.float32(1) / (np.float32(1) + np.float32(2.220446049250313e-16))
+    c2 = c * c
+    want = (((p[3] * c2 + p[2]) * c2 + p[1]) * c2 + p[0]) * c
+    assert f(1, 1) == want
+    assert abs(f(1, 1) - 44.9904) < 1e-3           # the polynomial's 45 degrees
+    rng = np.random.default_rng(2)
+    for _ in range(2000):
+        y, x = rng.normal(size=2).astype(np.float32) * 1000
+        true = np.degrees(np.arctan2(float(y), float(x))) % 360
+        got = f(y, x)
+        assert min(abs(got - true), 360 - abs(got - true)) < 0.02
+
+
+# ---------------------------------------------------------------- tables
+def test_tables():
+    e = orc.Extractor(1000, 1.2, 8, 20, 7)
+    assert list(e.features_per_level()) == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert list(e.umax()) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert list(orc.Extractor(1200).features_per_level()) == [261, 217, 181, 151, 126, 105, 87, 72]
+    assert list(orc.Extractor(2000).features_per_level()) == [434, 362, 302, 251, 209, 175, 145, 122]
+    s, inv, sg, isg = e.scale_factors()
+    assert s[0] == 1 and s[1] == np.float32(1.2) and s[2] == np.float32(np.float32(1.2) * np.float32(1.2))
+    assert np.all(inv == np.float32(1) / s) and np.all(sg == s * s)
+
+
+def test_level_sizes():
+    e = orc.Extractor()
+    e.extract(np.zeros((480, 752), np.uint8))
+    assert [e.level_size(l) for l in range(8)] == [(752, 480), (627, 400), (522, 333), (435, 278),
+                                                   (363, 231), (302, 193), (252, 161), (210, 134)]
+    e = orc.Extractor(2000)
+    e.extract(np.zeros((1080, 1920), np.uint8))
+    assert [e.level_size(l) for l in range(8)] == [(1920, 1080), (1600, 900), (1333, 750), (1111, 625),
+                                                   (926, 521), (772, 434), (643, 362), (536, 301)]
+
+
+# ---------------------------------------------------------------- resize
+def resize_numpy(src, dw, dh):
+    """Independent numpy restatement of the 11-bit fixed-point bilinear resize."""
+    sh, sw = src.shape
+
+    def tab(ssize, dsize, clamp):
+        scale = 1.0 / (np.float64(dsize) / ssize)
+        d = np.arange(dsize)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        if clamp:
+            f = np.where(s < 0, np.float32(0), f)
+            s = np.maximum(s, 0)
+            hi = s >= ssize - 1
+            f = np.where(hi, np.float32(0), f)
+            s = np.where(hi, ssize - 1, s)
+        w0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        w1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s, w0, w1
+
+    sx, a0, a1 = tab(sw, dw, True)
+    sy, b0, b1 = tab(sh, dh, False)
+    S = src.astype(np.int64)
+    sx1 = np.minimum(sx + 1, sw - 1)
+    H = S[:, sx] * a0 + S[:, sx1] * a1                     # (sh, dw)
+    r0 = H[np.clip(sy, 0, sh - 1)]
+    r1 = H[np.clip(sy + 1, 0, sh - 1)]
+    v = (((b0[:, None] * (r0 >> 4)) >> 16) + ((b1[:, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
+def test_resize_constant_and_numpy():
+    for v in (0, 1, 77, 128, 254, 255):
+        out = orc.resize(np.full((480, 752), v, np.uint8), 627, 400)
+        assert np.all(out == v)
+    rng = np.random.default_rng(3)
+    for (sw, sh, dw, dh) in [(752, 480, 627, 400), (627, 400, 522, 333), (101, 67, 84, 56), (40, 30, 33, 25)]:
+        src = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        assert np.array_equal(orc.resize(src, dw, dh), resize_numpy(src, dw, dh))
+
+
+# ---------------------------------------------------------------- blur
+def blur_numpy(src, taps):
+    K = np.array(taps, np.int64)
+    p = np.pad(src.astype(np.int64), 3, mode="reflect")      # numpy 'reflect' == BORDER_REFLECT_101
+    h, w = src.shape
+    t = sum(K[k] * p[:, k:k + w] for k in range(7))
+    t = np.minimum(t, 65535)
+    v = sum(K[k] * t[k:k + h, :] for k in range(7))
+    return np.minimum((v + 32768) >> 16, 255).astype(np.uint8)
+
+
+def test_blur_known_answers():
+    for v in (0, 1, 128, 200, 255):
+        img = np.full((40, 50), v, np.uint8)
+        assert np.all(orc.gaussian7(img, orc.BLUR_CV_4_2_PLUS) == v)
+        assert np.all(orc.gaussian7(img, orc.BLUR_CV_4_0_0) == min(255, (66049 * v + 32768) >> 16))
+    assert min(255, (66049 * 128 + 32768) >> 16) == 129
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    assert np.array_equal(orc.gaussian7(img, orc.BLUR_CV_4_0_0), blur_numpy(img, [18, 34, 49, 55, 49, 34, 18]))
+    assert np.array_equal(orc.gaussian7(img, orc.BLUR_CV_4_2_PLUS), blur_numpy(img, [18, 34, 48, 56, 48, 34, 18]))
+
+
+# ---------------------------------------------------------------- FAST
+CIRCLE = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2),
+          (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def strength_map(img):
+    """S(p) = max over the 16 arcs of 9 of min(d) and of min(-d), d = centre - circle pixel; defined on the
+    interior (3-px margin), 0 elsewhere.  p is a FAST corner at threshold t iff S > t; its score is S-1."""
+    h, w = img.shape
+    I = img.astype(np.int32)
+    c = I[3:h - 3, 3:w - 3]
+    d = np.stack([c - I[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx] for dx, dy in CIRCLE])   # (16, h-6, w-6)
+    d2 = np.concatenate([d, d[:8]])
+    A = np.max(np.stack([d2[k:k + 9].min(0) for k in range(16)]), 0)
+    B = np.max(np.stack([(-d2[k:k + 9]).min(0) for k in range(16)]), 0)
+    S = np.zeros((h, w), np.int32)
+    S[3:h - 3, 3:w - 3] = np.maximum(A, B)
+    return S
+
+
+def fast_numpy(img, t):
+    S = strength_map(img)
+    sc = np.where(S > t, S - 1, 0)
+    p = np.pad(sc, 1)
+    h, w = img.shape
+    nb = np.max(np.stack([p[1 + dy:1 + dy + h, 1 + dx:1 + dx + w] for dy in (-1, 0, 1) for dx in (-1, 0, 1)
+                          if (dx, dy) != (0, 0)]), 0)
+    ys, xs = np.nonzero((S > t) & (sc > nb))
+    return [(int(x), int(y), int(sc[y, x])) for y, x in zip(ys, xs)]
+
+
+def test_fast_single_pixel():
+    img = np.zeros((21, 21), np.uint8)
+    img[10, 10] = 255
+    for t in (1, 7, 20, 100, 254):
+        k = orc.fast(img, t)
+        assert [(p["x"], p["y"], p["response"]) for p in k] == [(10, 10, 254)]
+        assert k[0]["size"] == 7 and k[0]["angle"] == -1 and k[0]["octave"] == 0 and k[0]["class_id"] == -1
+    img[10, 11] = 255      # equal neighbours suppress each other
+    assert len(orc.fast(img, 20)) == 0
+    assert len(orc.fast(img, 7)) == 0
+    assert len(orc.fast(img, 20, nms=False)) == 2
+
+
+def test_fast_matches_strength_definition():
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        h, w = rng.integers(20, 60, 2)
+        base = rng.integers(0, 256, (h // 4 + 2, w // 4 + 2)).repeat(4, 0).repeat(4, 1)[:h, :w]
+        img = np.clip(base + rng.integers(-12, 13, (h, w)), 0, 255).astype(np.uint8)
+        for t in (7, 20, 40):
+            got = orc.fast(img, t)
+            want = fast_numpy(img, t)
+            assert [(int(p["x"]), int(p["y"]), int(p["response"])) for p in got] == want
+            S = strength_map(img)
+            nn = orc.fast(img, t, nms=False)
+            ys, xs = np.nonzero(S > t)
+            assert [(int(p["x"]), int(p["y"])) for p in nn] == [(int(x), int(y)) for y, x in zip(ys, xs)]
+
+
+# ---------------------------------------------------------------- quadtree
+def test_octree_properties():
+    rng = np.random.default_rng(6)
+    W, H = 720, 448
+    for n, N in [(0, 50), (1, 50), (5, 50), (300, 50), (3000, 217), (3000, 5000), (217, 217)]:
+        pts = set()
+        while len(pts) < n:
+            pts.add((int(rng.integers(3, W - 3)), int(rng.integers(3, H - 3))))
+        kps = np.zeros(n, orc.KP)
+        for i, (x, y) in enumerate(sorted(pts, key=lambda p: (p[1] // 32, p[0] // 30, p[1], p[0]))):
+            kps[i] = (x, y, 7, -1, int(rng.integers(7, 255)), 0, -1)
+        out = orc.distribute_octree(kps, 16, 16 + W, 16, 16 + H, N)
+        assert len(out) <= min(n, N + 3)
+        if n <= 1 or N >= 4 * n:
+            assert len(out) == n                      # every point ends alone in a node
+        elif n >= N:
+            assert len(out) >= min(N, n) or len(out) == n
+        src = {(p["x"], p["y"]): p["response"] for p in kps}
+        assert all(src[(p["x"], p["y"])] == p["response"] for p in out)
+        assert len({(p["x"], p["y"]) for p in out}) == len(out)
+        again = orc.distribute_octree(kps, 16, 16 + W, 16, 16 + H, N)
+        assert np.array_equal(out, again)
+
+
+def test_octree_keeps_strongest_first_on_ties():
+    # two points in one final node with equal response: the earlier one is kept
+    kps = np.zeros(3, orc.KP)
+    kps[0] = (10, 10, 7, -1, 50, 0, -1)
+    kps[1] = (11, 11, 7, -1, 50, 0, -1)
+    kps[2] = (500, 300, 7, -1, 20, 0, -1)
+    out = orc.distribute_octree(kps, 16, 736, 16, 464, 2)
+    assert len(out) == 2
+    assert (out["x"].tolist().count(10), out["x"].tolist().count(11)) == (1, 0)
+
+
+# ---------------------------------------------------------------- whole extractor
+def test_extract_degenerate_and_basic():
+    import my_orb_slam2_amd as m
+    e = orc.Extractor()
+    for kind in (m.synth.ZERO, m.synth.CONST128):
+        k, d = e.extract(m.synth_frame(0, kind=kind))
+        assert len(k) == 0
+    k, d = e.extract(None)
+    assert len(k) == 0
+    img = m.synth_frame(0)
+    k, d = e.extract(img)
+    assert 900 <= len(k) <= 1000 + 3 * 8
+    assert np.all(np.diff(k["octave"]) >= 0)                 # levels are concatenated in order
+    assert np.all((k["angle"] >= 0) & (k["angle"] < 360))
+    assert np.all(k["class_id"] == -1)
+    s = e.scale_factors()[0]
+    assert np.all(k["size"] == np.floor(31 * s[k["octave"]]))
+    # keypoints stay 19 px inside their level
+    for l in range(8):
+        w, h = e.level_size(l)
+        sel = e.level_selected(l)
+        assert np.all((sel["x"] >= 19) & (sel["x"] <= w - 20) & (sel["y"] >= 19) & (sel["y"] <= h - 20))
+    # the padded level is the level with a BORDER_REFLECT_101 frame
+    for l in (0, 3):
+        assert np.array_equal(e.level_image(l, padded=True), np.pad(e.level_image(l), 19, mode="reflect"))
+    # descriptor of a keypoint re-derived from the blurred level
+    k2, d2 = e.extract(img)
+    assert np.array_equal(k, k2) and np.array_equal(d, d2)
