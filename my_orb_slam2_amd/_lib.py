@@ -83,6 +83,14 @@ def lib():
         if not os.path.exists(path):
             raise ImportError("liborbx.so not built: run `make -C my_orb_slam2_amd/csrc` "
                               "(expected at %s)" % path)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 and liborbx.so is linked
+        # against the same SONAME. If torch is loaded first, liborbx binds to torch's copy and the two
+        # share devices, streams and allocations; loaded the other way round, the process ends up with
+        # two runtimes and torch then reports "No HIP GPUs are available". So load torch first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)

@@ -250,7 +250,7 @@ namespace {
 int ensure_staging(orbx_ctx* c, int cap) {
     const size_t B = (size_t)c->cfg.max_batch;
     if (!c->stageImg) {
-        int rc = dev_alloc(&c->stageImg, B * (size_t)c->cfg.max_width * c->cfg.max_height);
+        int rc = dev_alloc(&c->stageImg, B * (((size_t)c->cfg.max_width + 3) & ~(size_t)3) * c->cfg.max_height);
         if (rc) return rc;
         if ((rc = dev_alloc(&c->stageCounts, B))) return rc;
     }
