@@ -114,6 +114,15 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* images, int nframes, int wi
                        uint8_t* descriptors, int cap, int32_t* counts);
 int orbx_synchronize(orbx_ctx* ctx);
 
+/* Stage timing. The reference has no profiler; its examples only wrap std::chrono around Track*
+ * (orb_slam2_mono_example/mono_euroc.cc:96-105). With profiling enabled every batched call records
+ * HIP events on its launch stream around the four stages; orbx_get_stage_ms() waits for the last
+ * call and returns milliseconds for {pyramid (all resize launches), FAST cells, quadtree,
+ * orientation + descriptors}. */
+#define ORBX_NUM_STAGES 4
+int orbx_set_profiling(orbx_ctx* ctx, int enabled);
+int orbx_get_stage_ms(orbx_ctx* ctx, float* ms);
+
 /* mvImagePyramid[level] of frame `frame` of the last call (include/ORBextractor.h:100; read by
  * src/Frame.cc:510,600,612,617). With border != 0 the copy is (w+38) x (h+38) and carries the
  * 19-px BORDER_REFLECT_101 frame of src/ORBextractor.cc:1105-1120. dst is a host buffer. */

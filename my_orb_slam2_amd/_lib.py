@@ -54,6 +54,8 @@ SIGNATURES = {
     "orbx_extract_batch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                      _P, _P, C.c_int, _P]),
     "orbx_synchronize": (C.c_int, [_P]),
+    "orbx_set_profiling": (C.c_int, [_P, C.c_int]),
+    "orbx_get_stage_ms": (C.c_int, [_P, _P]),
     "orbx_level_size": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "orbx_get_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
     "orbx_debug_blur_level": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),

@@ -318,12 +318,10 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
 hipError_t launch_octree(const FrameSet& fs, const PyramidGeom& g, int nframes, hipStream_t s) {
     dim3 grid(g.nlevels, nframes, 1), block(kThreads, 1, 1);
     const size_t lds = octree_lds_bytes(g);
-    static bool attrSet = false;
-    if (!attrSet && lds > 64 * 1024) {
+    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it for this kernel
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attrSet = true;
     }
     hipLaunchKernelGGL(octree_kernel, grid, block, lds, s, fs, g);
     return hipGetLastError();

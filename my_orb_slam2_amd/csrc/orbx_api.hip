@@ -42,6 +42,10 @@ struct orbx_ctx {
     // last call
     int lastFrames = 0;
     hipStream_t lastStream = nullptr;
+    // stage timing
+    bool profiling = false;
+    bool haveTimes = false;
+    hipEvent_t ev[ORBX_NUM_STAGES + 1] = {};
 };
 
 namespace {
@@ -181,6 +185,8 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
                     c->fs.selCount, c->resizeBlob, c->stageImg, c->stageKps, c->stageDesc, c->stageCounts};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -239,10 +245,17 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, i
     c->lastFrames = nframes;
     c->lastStream = s;
     const PyramidGeom& g = c->geom;
+    const bool prof = c->profiling;
+    if (prof) HIP_TRY(hipEventRecord(c->ev[0], s));
     HIP_TRY(launch_pyramid(fs, g, c->resize, nframes, s));
+    if (prof) HIP_TRY(hipEventRecord(c->ev[1], s));
     HIP_TRY(launch_fast_cells(fs, g, nframes, c->cfg.ini_th_fast, c->cfg.min_th_fast, s));
+    if (prof) HIP_TRY(hipEventRecord(c->ev[2], s));
     HIP_TRY(launch_octree(fs, g, nframes, s));
+    if (prof) HIP_TRY(hipEventRecord(c->ev[3], s));
     HIP_TRY(launch_orient_desc(fs, g, nframes, c->cfg.blur_taps, d_kps, d_desc, cap, d_counts, s));
+    if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
+    c->haveTimes = prof;
     return ORBX_OK;
 }
 
@@ -328,6 +341,30 @@ extern "C" int orbx_synchronize(orbx_ctx* c) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->lastStream && c->lastStream != c->stream) HIP_TRY(hipStreamSynchronize(c->lastStream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_set_profiling(orbx_ctx* c, int enabled) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (enabled && !c->ev[0])
+        for (hipEvent_t& e : c->ev) HIP_TRY(hipEventCreate(&e));
+    c->profiling = enabled != 0;
+    c->haveTimes = false;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_get_stage_ms(orbx_ctx* c, float* ms) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!ms || !c->haveTimes) {
+        set_error("orbx_get_stage_ms: no profiled call yet");
+        return ORBX_ERR_STATE;
+    }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipEventSynchronize(c->ev[ORBX_NUM_STAGES]));
+    for (int i = 0; i < ORBX_NUM_STAGES; i++) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
     return ORBX_OK;
 }
 

@@ -134,6 +134,17 @@ class ORBextractor:
     def synchronize(self):
         check(lib().orbx_synchronize(self._ctx), "orbx_synchronize")
 
+    STAGES = ("pyramid", "fast_cells", "octree", "orient_desc")
+
+    def set_profiling(self, enabled=True):
+        check(lib().orbx_set_profiling(self._ctx, 1 if enabled else 0), "orbx_set_profiling")
+
+    def stage_ms(self):
+        """Milliseconds the four stages of the last profiled batched call took on the GPU."""
+        out = np.empty(4, dtype=np.float32)
+        check(lib().orbx_get_stage_ms(self._ctx, np_ptr(out)), "orbx_get_stage_ms")
+        return dict(zip(self.STAGES, out.tolist()))
+
     # ---- mvImagePyramid (include/ORBextractor.h:100) and stage probes ----
     def level_size(self, level):
         w, h = C.c_int(0), C.c_int(0)
