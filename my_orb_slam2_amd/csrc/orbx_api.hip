@@ -79,7 +79,7 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
     for (int l = 1; l < g.nlevels; l++) {
         build_resize_table(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h, ht[l]);
         bytes += up(ht[l].xofs.size() * 4) + up(ht[l].yofs.size() * 4) + up(ht[l].ialpha.size() * 2) +
-                 up(ht[l].ibeta.size() * 2);
+                 up(ht[l].ibeta.size() * 2) + up((ht[l].xofs.size() + 4) * 8);
     }
     std::vector<uint8_t> blob(std::max<size_t>(bytes, 64));
     HIP_TRY(hipStreamSynchronize(c->stream));   // the old tables may still be in use
@@ -100,6 +100,16 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
         c->resize[l].ialpha = reinterpret_cast<const int16_t*>(put(ht[l].ialpha.data(), ht[l].ialpha.size() * 2));
         c->resize[l].ibeta = reinterpret_cast<const int16_t*>(put(ht[l].ibeta.data(), ht[l].ibeta.size() * 2));
         c->resize[l].xmax = ht[l].xmax;
+        // packed per-column records, padded to a multiple of four with copies of the last column
+        const size_t n = ht[l].xofs.size(), n4 = (n + 3) / 4 * 4;
+        std::vector<int32_t> xe(2 * n4);
+        for (size_t i = 0; i < n4; i++) {
+            const size_t j = std::min(i, n - 1);
+            xe[2 * i] = ht[l].xofs[j];
+            xe[2 * i + 1] = (int32_t)((uint32_t)(uint16_t)ht[l].ialpha[2 * j] |
+                                      ((uint32_t)(uint16_t)ht[l].ialpha[2 * j + 1] << 16));
+        }
+        c->resize[l].xentry = reinterpret_cast<const int32_t*>(put(xe.data(), xe.size() * 4));
     }
     HIP_TRY(hipMemcpy(c->resizeBlob, blob.data(), blob.size(), hipMemcpyHostToDevice));
     c->geom = g;

@@ -66,6 +66,7 @@ struct FrameSet {
 // Bilinear resize tables of one level (cv::resize INTER_LINEAR, 8U fixed point).
 struct ResizeTab {
     const int32_t* xofs;    // [dw]
+    const int32_t* xentry;  // [dw rounded up to 4][2]: {xofs, ialpha0 | ialpha1 << 16}
     const int16_t* ialpha;  // [dw][2]
     const int32_t* yofs;    // [dh]
     const int16_t* ibeta;   // [dh][2]

@@ -3,13 +3,16 @@
 // GaussianBlur :1077-1078; computeOrbDescriptor :99-139; final scaling and concatenation
 // :1067-1096).
 //
-// The reference blurs every whole level and then samples 512 pixels per keypoint. Here the wave
-// stages the 43x43 raw patch around its keypoint in LDS (radius 15 for the moments, 18 for the
-// rotated pattern, +3 for the 7x7 taps) and evaluates the fixed-point Gaussian only at the 512
-// sampled positions; the separable 8.8 fixed-point filter has no intermediate rounding
-// (u16 row sums, 16.16 column sums), so a direct 7x7 evaluation gives the same byte. No blurred
-// level is ever written to HBM. orbx_debug_blur_level() runs the same arithmetic over a full
-// level for parity tests.
+// The reference blurs every whole level and then samples 512 pixels per keypoint. Here a wave
+// stages the 43-row patch around its keypoint in LDS (radius 15 for the moments, 18 for the
+// rotated pattern, +3 for the 7x7 taps), blurs it there with the same separable 8.8 fixed-point
+// filter (u16 row sums, 16.16 column sums, one rounding at the end: cv fixedSmoothInvoker), and
+// samples the blurred patch. No blurred level is ever written to HBM.
+//   R  raw bytes, 43 rows x 48 B, columns aligned to a dword of the image row (coalesced dword loads)
+//   T  row sums as u32, 43 x 44: four outputs per lane from three dwords via v_alignbyte + v_dot4_u32_u8
+//   Bl blurred bytes, 37 x 44 (overlays R once the row pass is done): four outputs per lane from
+//      seven 16-byte reads and v_mad_u32_u24
+// orbx_debug_blur_level() runs the same arithmetic over a full level for parity tests.
 #include "orbx_internal.h"
 
 namespace orbx {
@@ -22,10 +25,14 @@ __device__ const int8_t c_pattern[1024] = {
 
 __constant__ int c_umax[kHalfPatch + 1] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
-constexpr int kPR = 21;               // patch radius
-constexpr int kPW = 2 * kPR + 1;      // 43
-constexpr int kPitch = 48;            // LDS row pitch of the patch (bytes)
+constexpr int kPR = 21;                 // patch radius
+constexpr int kRows = 2 * kPR + 1;      // 43 patch rows
+constexpr int kRPitch = 48;             // bytes per raw row (12 dwords)
+constexpr int kTPitch = 44;             // u32 per row of T, bytes per row of Bl
+constexpr int kGroups = 11;             // 4-column groups per row: columns 0..43
+constexpr int kBlRows = 37;             // blurred rows: patch rows 3..39
 constexpr int kWavesPerBlock = 4;
+constexpr int kWaveLds = kRows * kRPitch + kRows * kTPitch * 4;   // 2064 + 7568 bytes
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     p = p < 0 ? -p : p;
@@ -53,37 +60,22 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-// 7x7 fixed-point Gaussian at patch position (px, py): cv fixedSmoothInvoker<uint8_t, ufixedpoint16>
-__device__ __forceinline__ int blur_at(const uint8_t* patch, int px, int py, const int* K) {
-    const uint8_t* p = patch + (py - 3) * kPitch + (px - 3);
-    unsigned acc = 0;
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-        unsigned h = 0;
-#pragma unroll
-        for (int c = 0; c < 7; c++) h += (unsigned)K[c] * p[r * kPitch + c];
-        acc += (unsigned)K[r] * min(h, 0xFFFFu);
-    }
-    return (int)min((acc + 32768u) >> 16, 255u);
-}
-
 }  // namespace
 
+template <bool ALIGNED4>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameSet fs, PyramidGeom g,
                                                                            int blurTaps,
                                                                            orbx_keypoint* __restrict__ kpsOut,
                                                                            uint8_t* __restrict__ descOut, int cap,
                                                                            int32_t* __restrict__ countsOut) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[kWavesPerBlock][kPW * kPitch];
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kWavesPerBlock * kWaveLds];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int f = blockIdx.y;
     const int slot = blockIdx.x * kWavesPerBlock + wv;    // index into the frame's selected regions
-    // No wave leaves before the barrier below; inactive waves just skip the work.
+    // No wave leaves before the last barrier; inactive waves just skip the work.
     bool active = slot < g.totalSel;
-    int l = 0, k = 0, outIdx = 0, kx = 0, ky = 0;
+    int l = 0, k = 0, outIdx = 0, kx = 0, ky = 0, cx = kPR;
     uint32_t packed = 0;
-    const uint8_t* img = nullptr;
-    long long rowStride = 0;
     if (active) {
         while (l + 1 < g.nlevels && slot >= g.lv[l + 1].selBase) l++;
         k = slot - g.lv[l].selBase;
@@ -100,11 +92,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
         active = k < selCount[l] && outIdx < cap;
     }
     const LevelGeom& L = g.lv[l];
-    uint8_t* patch = s_patch[wv];
+    uint8_t* R = s_mem + wv * kWaveLds;                                   // raw patch, later Bl
+    uint32_t* T = reinterpret_cast<uint32_t*>(R + kRows * kRPitch);      // row sums
     if (active) {
         packed = fs.sel[(long long)f * g.totalSel + slot];
         kx = cand_x(packed) + kBorder;   // level coordinates (:835-836)
         ky = cand_y(packed) + kBorder;
+        const uint8_t* img;
+        long long rowStride;
         if (l == 0) {
             img = fs.img + (long long)f * fs.imgFrameStride;
             rowStride = fs.imgRowStride;
@@ -112,53 +107,130 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
             img = fs.pyr + (long long)f * g.pyrBytes + L.offset;
             rowStride = L.stride;
         }
-        // stage the raw patch; coordinates outside the level are reflected (BORDER_REFLECT_101)
-        for (int i = lane; i < kPW * kPW; i += 64) {
-            const int r = i / kPW, c = i - r * kPW;
-            const int sy = reflect101(ky - kPR + r, L.h), sx = reflect101(kx - kPR + c, L.w);
-            patch[r * kPitch + c] = img[(long long)sy * rowStride + sx];
+        // ---- stage the raw patch: LDS column j <-> image column xa + j, LDS row r <-> image row ky-21+r ----
+        const int xa = (kx - kPR) & ~3;
+        const bool interior = kx - kPR >= 0 && kx + kPR < L.w && ky - kPR >= 0 && ky + kPR < L.h &&
+                              xa + kRPitch <= rowStride && (ALIGNED4 || l > 0);
+        if (interior) {
+            cx = kx - xa;
+            const uint8_t* src = img + (long long)(ky - kPR) * rowStride + xa;
+            uint32_t* R32 = reinterpret_cast<uint32_t*>(R);
+            // all loads are issued before the first LDS store so their latencies overlap
+            constexpr int kIter = (kRows * 12 + 63) / 64;
+            uint32_t v[kIter];
+#pragma unroll
+            for (int q = 0; q < kIter; q++) {
+                const int i = min(lane + 64 * q, kRows * 12 - 1);
+                const int r = i / 12, d = i - r * 12;
+                v[q] = *reinterpret_cast<const uint32_t*>(src + (long long)r * rowStride + d * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < kIter; q++)
+                if (lane + 64 * q < kRows * 12) R32[lane + 64 * q] = v[q];
+        } else {
+            // near the level border or unaligned caller memory: bytes, BORDER_REFLECT_101 coordinates
+            cx = kPR;
+            for (int i = lane; i < kRows * kRPitch; i += 64) {
+                const int r = i / kRPitch, c = i - r * kRPitch;
+                const int sy = reflect101(ky - kPR + r, L.h), sx = reflect101(kx - kPR + c, L.w);
+                R[i] = img[(long long)sy * rowStride + sx];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- intensity centroid on the unblurred patch (:69-96) ----
+    float angle = 0.f;
+    if (active) {
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int q = 0; q < (kPatchSize * kPatchSize + 63) / 64; q++) {
+            const int i = lane + 64 * q;
+            const int v = i / kPatchSize - kHalfPatch, u = i - (v + kHalfPatch) * kPatchSize - kHalfPatch;
+            if (i < kPatchSize * kPatchSize && abs(u) <= c_umax[abs(v)]) {
+                const int val = R[(kPR + v) * kRPitch + cx + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            m10 += __shfl_xor(m10, off);
+            m01 += __shfl_xor(m01, off);
+        }
+        angle = fast_atan2_deg((float)m01, (float)m10);
+
+        // ---- row pass: T[r][j] = sum_c K[c] * R[r][j-3+c], four columns per lane ----
+        const uint32_t klo = blurTaps == ORBX_BLUR_CV_4_0_0 ? 0x37312212u : 0x38302212u;  // K0..K3
+        const uint32_t khi = blurTaps == ORBX_BLUR_CV_4_0_0 ? 0x00122231u : 0x00122230u;  // K4..K6
+        const uint32_t* R32 = reinterpret_cast<const uint32_t*>(R);
+#pragma unroll
+        for (int q = 0; q < (kRows * kGroups + 63) / 64; q++) {
+            const int i = lane + 64 * q;
+            if (i >= kRows * kGroups) break;
+            const int r = i / kGroups, gq = i - r * kGroups;
+            const uint32_t A = gq ? R32[r * 12 + gq - 1] : 0u;   // columns 4g-4 .. 4g-1
+            const uint32_t B = R32[r * 12 + gq];                 // columns 4g   .. 4g+3
+            const uint32_t C = R32[r * 12 + gq + 1];             // columns 4g+4 .. 4g+7
+            uint4 o;
+            o.x = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 1), klo,
+                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 1), khi, 0u, false), false);
+            o.y = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 2), klo,
+                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 2), khi, 0u, false), false);
+            o.z = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 3), klo,
+                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 3), khi, 0u, false), false);
+            o.w = __builtin_amdgcn_udot4(B, klo, __builtin_amdgcn_udot4(C, khi, 0u, false), false);
+            *reinterpret_cast<uint4*>(T + r * kTPitch + 4 * gq) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- column pass: Bl[y][j] = min(255, (sum_r K[r] * T[y+r][j] + 32768) >> 16), y = patch row - 3 ----
+    if (active) {
+        const uint32_t k0 = 18, k1 = 34, k2 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 49 : 48,
+                       k3 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 55 : 56;
+        const uint32_t kk[7] = {k0, k1, k2, k3, k2, k1, k0};
+        uint32_t* Bl32 = reinterpret_cast<uint32_t*>(R);
+#pragma unroll
+        for (int q = 0; q < (kBlRows * kGroups + 63) / 64; q++) {
+            const int i = lane + 64 * q;
+            if (i >= kBlRows * kGroups) break;
+            const int y = i / kGroups, gq = i - y * kGroups;
+            uint4 acc = make_uint4(32768u, 32768u, 32768u, 32768u);
+#pragma unroll
+            for (int r = 0; r < 7; r++) {
+                const uint4 t = *reinterpret_cast<const uint4*>(T + (y + r) * kTPitch + 4 * gq);
+                acc.x += kk[r] * t.x;
+                acc.y += kk[r] * t.y;
+                acc.z += kk[r] * t.z;
+                acc.w += kk[r] * t.w;
+            }
+            Bl32[y * (kTPitch / 4) + gq] = min(acc.x >> 16, 255u) | (min(acc.y >> 16, 255u) << 8) |
+                                           (min(acc.z >> 16, 255u) << 16) | (min(acc.w >> 16, 255u) << 24);
         }
     }
     __syncthreads();
     if (!active) return;
 
-    // ---- intensity centroid on the unblurred patch (:69-96) ----
-    int m10 = 0, m01 = 0;
-    for (int i = lane; i < kPatchSize * kPatchSize; i += 64) {
-        const int v = i / kPatchSize - kHalfPatch, u = i - (v + kHalfPatch) * kPatchSize - kHalfPatch;
-        if (abs(u) <= c_umax[abs(v)]) {
-            const int val = patch[(kPR + v) * kPitch + kPR + u];
-            m10 += u * val;
-            m01 += v * val;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        m10 += __shfl_xor(m10, off);
-        m01 += __shfl_xor(m01, off);
-    }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
     // ---- steered BRIEF on the blurred patch (:99-139) ----
-    const int K0[7] = {18, 34, 49, 55, 49, 34, 18};
-    const int K1[7] = {18, 34, 48, 56, 48, 34, 18};
-    int K[7];
-#pragma unroll
-    for (int i = 0; i < 7; i++) K[i] = blurTaps == ORBX_BLUR_CV_4_0_0 ? K0[i] : K1[i];
+    const uint8_t* Bl = R;
     const float rad = __fmul_rn(angle, (float)(3.14159265358979323846 / 180.f));
-    const float a = (float)cos((double)rad), b = (float)sin((double)rad);
+    double sd, cd;
+    sincos((double)rad, &sd, &cd);
+    const float a = (float)cd, b = (float)sd;
     unsigned long long* desc64 = reinterpret_cast<unsigned long long*>(descOut + ((long long)f * cap + outIdx) * 32);
-#pragma unroll 1
+    const int base = (kPR - 3) * kTPitch + cx;   // blurred row y <-> patch row y + 3
+#pragma unroll
     for (int round = 0; round < 4; round++) {
         const int pair = round * 64 + lane;
-        const int8_t* pt = c_pattern + 4 * pair;
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const char4 pt = *reinterpret_cast<const char4*>(c_pattern + 4 * pair);
+        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = blur_at(patch, kPR + c0, kPR + r0, K);
-        const int t1 = blur_at(patch, kPR + c1, kPR + r1, K);
+        const int t0 = Bl[base + r0 * kTPitch + c0];
+        const int t1 = Bl[base + r1 * kTPitch + c1];
         const unsigned long long bits = __ballot(t0 < t1);
         if (lane == 0) desc64[round] = bits;   // pair 64*round + j is bit j%8 of byte 8*round + j/8
     }
@@ -198,7 +270,11 @@ __global__ __launch_bounds__(256) void blur_level_kernel(const uint8_t* __restri
 hipError_t launch_orient_desc(const FrameSet& fs, const PyramidGeom& g, int nframes, int blurTaps,
                               orbx_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, hipStream_t s) {
     dim3 grid((g.totalSel + kWavesPerBlock - 1) / kWavesPerBlock, nframes, 1), block(64 * kWavesPerBlock, 1, 1);
-    hipLaunchKernelGGL(orient_desc_kernel, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts);
+    const bool aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
+    if (aligned)
+        hipLaunchKernelGGL(orient_desc_kernel<true>, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts);
+    else
+        hipLaunchKernelGGL(orient_desc_kernel<false>, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts);
     return hipGetLastError();
 }
 
