@@ -25,7 +25,8 @@ namespace {
 __device__ __forceinline__ int div_small(int i, int recip) { return (int)(((unsigned)i * (unsigned)recip) >> 16); }
 
 // Corner strength of the pixel at p (LDS, row pitch `pitch`): see step 3 above.
-__device__ __forceinline__ int corner_strength(const uint8_t* p, int pitch) {
+template <int pitch>
+__device__ __forceinline__ int corner_strength(const uint8_t* p) {
     const int v = p[0];
     int d[16];
     d[0] = v - p[3 * pitch];
@@ -61,7 +62,9 @@ __device__ __forceinline__ int corner_strength(const uint8_t* p, int pitch) {
 
 }  // namespace
 
-template <bool ALIGNED4>
+// PITCH is the LDS row pitch of the staged cell (bytes, multiple of 4); a compile-time constant so that
+// all sixteen circle offsets fold into the ds_read immediate offsets.
+template <bool ALIGNED4, int PITCH>
 __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom g, int iniTh, int minTh) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x;
@@ -99,11 +102,11 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
 
     // ---- 1. stage the cell in LDS ----
     uint8_t* tile = smem;
-    int pitch, xo;
+    constexpr int pitch = PITCH;
+    int xo;
     if (ALIGNED4) {
         const int xa = iniX & ~3;
         const int ndw = (maxX - xa + 3) >> 2;
-        pitch = ndw * 4;
         xo = iniX - xa;
         const int total = ndw * th;
         const int recip = (65536 + ndw - 1) / ndw;
@@ -111,11 +114,11 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
         for (int i = lane; i < total; i += 64) {
             const int y = div_small(i, recip);
             const int dwi = i - y * ndw;
-            tile32[i] = *reinterpret_cast<const uint32_t*>(img + (long long)(iniY + y) * rowStride + xa + dwi * 4);
+            tile32[y * (PITCH / 4) + dwi] =
+                *reinterpret_cast<const uint32_t*>(img + (long long)(iniY + y) * rowStride + xa + dwi * 4);
         }
     } else {
         const int tw = maxX - iniX;
-        pitch = (tw + 3) & ~3;
         xo = 0;
         const int recip = (65536 + tw - 1) / tw;
         for (int i = lane; i < tw * th; i += 64) {
@@ -139,13 +142,15 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
     const int recipSw = (65536 + sw - 1) / sw;
     const int tlow = min(iniTh, minTh);
     int nq = 0;
+    // lane's pixel (x, y) advances by 64 positions per iteration without any multiply
+    const int dy64 = 64 / sw, dx64 = 64 - dy64 * sw;
+    int py = div_small(lane, recipSw), px = lane - py * sw;
+    int addr = (py + 3) * pitch + xo + px + 3;
     for (int base = 0; base < npix; base += 64) {
         const int i = base + lane;
         bool pass = false;
         if (i < npix) {
-            const int y = div_small(i, recipSw);
-            const int x = i - y * sw;
-            const uint8_t* p = tile + (y + 3) * pitch + xo + x + 3;
+            const uint8_t* p = tile + addr;
             const int v = p[0];
             // circle pixel k and its antipode k+8: a run of 9 holds at least one of each pair
             const int p0 = p[3 * pitch], p8 = p[-3 * pitch];
@@ -166,6 +171,12 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
                 pass = mnmax < v - tlow || mxmin > v + tlow;
             }
         }
+        px += dx64;
+        addr += dy64 * pitch + dx64;
+        if (px >= sw) {
+            px -= sw;
+            addr += pitch - sw;
+        }
         const unsigned long long m = __ballot(pass);
         if (pass) queue[nq + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
         nq += __popcll(m);
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
             i = queue[qi];
             const int y = div_small(i, recipSw);
             const int x = i - y * sw;
-            S = corner_strength(tile + (y + 3) * pitch + xo + x + 3, pitch);
+            S = corner_strength<PITCH>(tile + (y + 3) * pitch + xo + x + 3);
             if (S > tlow) score[(y + 1) * sp + x + 1] = (uint8_t)S; else S = 0;
         }
         const unsigned long long m = __ballot(S > 0);
@@ -233,10 +244,15 @@ hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nfram
     const size_t lds = (size_t)g.maxTileBytes + g.maxScoreBytes + 2 * (size_t)g.maxScanPix + 16;
     dim3 grid(g.totalCells, nframes, 1), block(64, 1, 1);
     const bool aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
-    if (aligned)
-        hipLaunchKernelGGL(fast_cells_kernel<true>, grid, block, lds, s, fs, g, iniTh, minTh);
+    const bool small = g.tilePitch == 48;
+    if (aligned && small)
+        hipLaunchKernelGGL((fast_cells_kernel<true, 48>), grid, block, lds, s, fs, g, iniTh, minTh);
+    else if (aligned)
+        hipLaunchKernelGGL((fast_cells_kernel<true, 80>), grid, block, lds, s, fs, g, iniTh, minTh);
+    else if (small)
+        hipLaunchKernelGGL((fast_cells_kernel<false, 48>), grid, block, lds, s, fs, g, iniTh, minTh);
     else
-        hipLaunchKernelGGL(fast_cells_kernel<false>, grid, block, lds, s, fs, g, iniTh, minTh);
+        hipLaunchKernelGGL((fast_cells_kernel<false, 80>), grid, block, lds, s, fs, g, iniTh, minTh);
     return hipGetLastError();
 }
 

@@ -81,7 +81,7 @@ bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g,
     g.width = width;
     g.height = height;
     long long pyr = 0, slots = 0;
-    int cells = 0, sel = 0;
+    int cells = 0, sel = 0, maxWCell = 0, maxHCell = 0;
     g.nodeCap = 16;
     for (int l = 0; l < nlevels; l++) {
         LevelGeom& L = g.lv[l];
@@ -119,8 +119,8 @@ bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g,
         sel += L.quota + kSelPad;
         g.nodeCap = std::max(g.nodeCap, std::max(L.quota + 8, 4 * nIni + 8));
         if (nCols) {
-            const int ndw = (3 + L.wCell + 6 + 3) >> 2;
-            g.maxTileBytes = std::max(g.maxTileBytes, 4 * ndw * (L.hCell + 6));
+            maxWCell = std::max(maxWCell, L.wCell);
+            maxHCell = std::max(maxHCell, L.hCell);
             g.maxScanPix = std::max(g.maxScanPix, L.wCell * L.hCell);
             g.maxScoreBytes = std::max(g.maxScoreBytes, align_up((L.wCell + 2) * (L.hCell + 2), 4));
         }
@@ -129,6 +129,10 @@ bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g,
             return false;
         }
     }
+    // A staged cell row holds up to 3 bytes of alignment slack + the cell + 6 px, rounded up to
+    // dwords; every level of a launch uses the same pitch: 48 bytes when all cells fit, else 80.
+    g.tilePitch = ((3 + maxWCell + 6 + 3) & ~3) <= 48 ? 48 : 80;
+    g.maxTileBytes = g.tilePitch * (maxHCell + 6);
     g.totalCells = cells;
     g.totalSlots = slots;
     g.totalSel = sel;

@@ -1,0 +1,27 @@
+// Exercises the C++ shim the way Frame::ExtractORB does and prints a digest that the Python test
+// compares with the oracle's result for the same synthetic frame.
+#include <cstdio>
+#include <vector>
+
+#include "ORBextractorGpu.h"
+
+int main() {
+    const int W = 752, H = 480;
+    std::vector<uint8_t> img(static_cast<size_t>(W) * H);
+    if (orbx_synth_frame(0, W, H, ORBX_SYNTH_SCENE, 300, 40, 0, img.data(), W) != ORBX_OK) return 2;
+    ORB_SLAM2::ORBextractorGpu ex(1000, 1.2f, 8, 20, 7, 0, W, H);
+    std::vector<orbx_keypoint> k;
+    std::vector<uint8_t> d;
+    ex(img.data(), W, H, W, k, d, true);
+    unsigned long long h = 1469598103934665603ull;   // FNV-1a over descriptors
+    for (uint8_t b : d) { h ^= b; h *= 1099511628211ull; }
+    std::printf("n=%zu levels=%d scale1=%.9g desc_fnv=%016llx kp0=(%.1f,%.1f,%.6f) pyr1=%dx%d px=%d dist=%d\n",
+                k.size(), ex.GetLevels(), ex.GetScaleFactors()[1], h, k[0].x, k[0].y, k[0].angle,
+                ex.mvImagePyramid[1].cols, ex.mvImagePyramid[1].rows, (int)ex.mvImagePyramid[1].ptr()[0],
+                ORB_SLAM2::DescriptorDistance(d.data(), d.data() + 32));
+    // empty image: outputs untouched
+    std::vector<orbx_keypoint> k2(3);
+    std::vector<uint8_t> d2(5);
+    ex(nullptr, 0, 0, 0, k2, d2);
+    return (k2.size() == 3 && d2.size() == 5) ? 0 : 3;
+}

@@ -186,3 +186,47 @@ def test_two_contexts_like_stereo():
     ckr, cdr = cpu.extract(fr)
     assert np.array_equal(dl, cdl) and np.array_equal(dr, cdr)
     assert np.array_equal(kl["x"], ckl["x"]) and np.array_equal(kr["y"], ckr["y"])
+
+
+def test_against_stored_golden_vectors():
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, idx, w, h, nf in [("extract_752x480_f0", 0, 752, 480, 1000), ("extract_321x243_f11", 11, 321, 243, 500)]:
+        g = np.load(os.path.join(gdir, name + ".npz"))
+        gpu = m.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+        k, d = gpu(m.synth_frame(idx, w, h))
+        gk = g["keypoints"]
+        assert len(k) == len(gk)
+        for f in ("x", "y", "size", "response", "octave", "class_id"):
+            assert np.array_equal(k[f], gk[f])
+        assert np.abs(k["angle"] - gk["angle"]).max() <= ANGLE_TOL_DEG
+        assert np.array_equal(d, g["descriptors"])
+    g = np.load(os.path.join(gdir, "knn2_256x4096.npz"))
+    idx, d1, d2 = m.HammingMatcher().knn2(g["query"], g["db"])
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(d1, g["d1"]) and np.array_equal(d2, g["d2"])
+
+
+def test_cpp_shim_program():
+    """tests/cpp/test_shim.cpp drives ORBextractorGpu (the C++ mirror of the reference class)."""
+    import os
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_shim")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stderr
+    cpu = orc.Extractor()
+    k, d = cpu.extract(m.synth_frame(0))
+    h = 1469598103934665603
+    for b in d.tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    mt = re.search(r"n=(\d+) levels=(\d+) scale1=(\S+) desc_fnv=(\w+) kp0=\((\S+),(\S+),(\S+)\) pyr1=(\d+)x(\d+) px=(\d+) dist=(\d+)",
+                   out.stdout)
+    assert mt, out.stdout
+    assert int(mt.group(1)) == len(k) and int(mt.group(2)) == 8
+    assert mt.group(4) == "%016x" % h
+    assert float(mt.group(5)) == k["x"][0] and float(mt.group(6)) == k["y"][0]
+    assert abs(float(mt.group(7)) - k["angle"][0]) < 1e-3
+    assert (int(mt.group(8)), int(mt.group(9))) == cpu.level_size(1)
+    assert int(mt.group(10)) == int(cpu.level_image(1)[0, 0])
+    assert int(mt.group(11)) == orc.hamming(d[0], d[1])

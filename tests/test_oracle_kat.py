@@ -291,3 +291,19 @@ def test_extract_degenerate_and_basic():
     # descriptor of a keypoint re-derived from the blurred level
     k2, d2 = e.extract(img)
     assert np.array_equal(k, k2) and np.array_equal(d, d2)
+
+
+# ---------------------------------------------------------------- stored regression vectors
+def test_oracle_reproduces_golden_vectors():
+    import os
+    import my_orb_slam2_amd as m
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, idx, w, h, nf in [("extract_752x480_f0", 0, 752, 480, 1000), ("extract_321x243_f11", 11, 321, 243, 500)]:
+        g = np.load(os.path.join(gdir, name + ".npz"))
+        e = orc.Extractor(nf, 1.2, 8, 20, 7, orc.BLUR_CV_4_0_0)
+        k, d = e.extract(m.synth_frame(idx, w, h))
+        assert np.array_equal(k, g["keypoints"]) and np.array_equal(d, g["descriptors"])
+        assert [list(e.level_size(l)) for l in range(8)] == g["level_sizes"].tolist()
+    g = np.load(os.path.join(gdir, "knn2_256x4096.npz"))
+    idx, d1, d2 = orc.knn2(g["query"], g["db"])
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(d1, g["d1"]) and np.array_equal(d2, g["d2"])
