@@ -23,16 +23,43 @@ __device__ const int8_t c_pattern[1024] = {
 #include "../../include/orbx_pattern31.inc"
 };
 
-__constant__ int c_umax[kHalfPatch + 1] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// End of each row of the radius-15 disc (umax, src/ORBextractor.cc:446-461).
+constexpr int kUmax[kHalfPatch + 1] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+// Byte weights for the intensity-centroid sums, four columns per dword: row |v| (16) x dword q (8),
+// column u = 4q - 15 + byte. Set 0: 1 inside the disc (plain row sum); set 1: u + 15 inside the disc.
+struct MomentWeights {
+    uint32_t w[2][16][8];
+};
+constexpr MomentWeights make_moment_weights() {
+    MomentWeights m{};
+    for (int av = 0; av < 16; av++)
+        for (int q = 0; q < 8; q++) {
+            uint32_t w0 = 0, w1 = 0;
+            for (int b = 0; b < 4; b++) {
+                const int u = 4 * q - 15 + b;
+                const int au = u < 0 ? -u : u;
+                if (au <= kUmax[av]) {
+                    w0 |= 1u << (8 * b);
+                    w1 |= (uint32_t)(u + 15) << (8 * b);
+                }
+            }
+            m.w[0][av][q] = w0;
+            m.w[1][av][q] = w1;
+        }
+    return m;
+}
+__device__ const MomentWeights c_momw = make_moment_weights();
 
 constexpr int kPR = 21;                 // patch radius
 constexpr int kRows = 2 * kPR + 1;      // 43 patch rows
 constexpr int kRPitch = 48;             // bytes per raw row (12 dwords)
 constexpr int kTPitch = 44;             // u32 per row of T, bytes per row of Bl
-constexpr int kGroups = 11;             // 4-column groups per row: columns 0..43
+constexpr int kGroups = 10;             // 4-column groups blurred per row (40 columns cover cx-18..cx+18)
 constexpr int kBlRows = 37;             // blurred rows: patch rows 3..39
 constexpr int kWavesPerBlock = 4;
 constexpr int kWaveLds = kRows * kRPitch + kRows * kTPitch * 4;   // 2064 + 7568 bytes
+constexpr int kMomLds = 2 * 16 * 8 * 4;                             // moment weights, shared by the block
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     p = p < 0 ? -p : p;
@@ -68,10 +95,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
                                                                            orbx_keypoint* __restrict__ kpsOut,
                                                                            uint8_t* __restrict__ descOut, int cap,
                                                                            int32_t* __restrict__ countsOut) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kWavesPerBlock * kWaveLds];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kWavesPerBlock * kWaveLds + kMomLds];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the set-up scalar
     const int f = blockIdx.y;
     const int slot = blockIdx.x * kWavesPerBlock + wv;    // index into the frame's selected regions
+    uint32_t* momw = reinterpret_cast<uint32_t*>(s_mem + kWavesPerBlock * kWaveLds);
+    momw[threadIdx.x] = (&c_momw.w[0][0][0])[threadIdx.x];
     // No wave leaves before the last barrier; inactive waves just skip the work.
     bool active = slot < g.totalSel;
     int l = 0, k = 0, outIdx = 0, kx = 0, ky = 0, cx = kPR;
@@ -113,16 +143,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
                               xa + kRPitch <= rowStride && (ALIGNED4 || l > 0);
         if (interior) {
             cx = kx - xa;
-            const uint8_t* src = img + (long long)(ky - kPR) * rowStride + xa;
             uint32_t* R32 = reinterpret_cast<uint32_t*>(R);
-            // all loads are issued before the first LDS store so their latencies overlap
+            // lane + 64q -> (row, dword): 64 = 5*12 + 4, so both advance without a division; all loads
+            // are issued before the first LDS store so their latencies overlap
             constexpr int kIter = (kRows * 12 + 63) / 64;
+            int r = lane / 12, d = lane - r * 12;
+            const uint8_t* src = img + (long long)(ky - kPR + r) * rowStride + xa + d * 4;
             uint32_t v[kIter];
 #pragma unroll
             for (int q = 0; q < kIter; q++) {
-                const int i = min(lane + 64 * q, kRows * 12 - 1);
-                const int r = i / 12, d = i - r * 12;
-                v[q] = *reinterpret_cast<const uint32_t*>(src + (long long)r * rowStride + d * 4);
+                v[q] = r < kRows ? *reinterpret_cast<const uint32_t*>(src) : 0u;
+                d += 4;
+                r += 5;
+                src += 5 * rowStride + 16;
+                if (d >= 12) {
+                    d -= 12;
+                    r += 1;
+                    src += rowStride - 48;
+                }
             }
 #pragma unroll
             for (int q = 0; q < kIter; q++)
@@ -141,18 +179,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
 
     // ---- intensity centroid on the unblurred patch (:69-96) ----
     float angle = 0.f;
+    const int g0 = (cx - 18) >> 2;     // first blurred 4-column group: columns 4*g0 .. 4*g0+39 cover cx-18 .. cx+18
     if (active) {
-        int m10 = 0, m01 = 0;
+        // m01 = sum v*I, m10 = sum u*I over the disc; each lane takes dwords (four columns) of the 31x31
+        // window: row sums with 0/1 byte weights, sum (u+15)*I with byte weights, both by v_dot4_u32_u8
+        const uint32_t* R32 = reinterpret_cast<const uint32_t*>(R);
+        const int c0 = cx - kHalfPatch;            // first column of the window
+        const uint32_t sh = (uint32_t)(c0 & 3);
+        int s0 = 0, s1 = 0, m01 = 0;
 #pragma unroll
-        for (int q = 0; q < (kPatchSize * kPatchSize + 63) / 64; q++) {
-            const int i = lane + 64 * q;
-            const int v = i / kPatchSize - kHalfPatch, u = i - (v + kHalfPatch) * kPatchSize - kHalfPatch;
-            if (i < kPatchSize * kPatchSize && abs(u) <= c_umax[abs(v)]) {
-                const int val = R[(kPR + v) * kRPitch + cx + u];
-                m10 += u * val;
-                m01 += v * val;
+        for (int q = 0; q < 4; q++) {
+            const int i = lane + 64 * q;           // 31 rows x 8 dwords = 248 items
+            if (i < 31 * 8) {
+                const int row = i >> 3, dq = i & 7;
+                const int v = row - kHalfPatch, av = abs(v);
+                const int di = (kPR + v) * 12 + (c0 >> 2) + dq;
+                const uint32_t D = __builtin_amdgcn_alignbyte(R32[di + 1], R32[di], sh);
+                const uint32_t rs = __builtin_amdgcn_udot4(D, momw[av * 8 + dq], 0u, false);
+                s0 += (int)rs;
+                m01 += v * (int)rs;
+                s1 = (int)__builtin_amdgcn_udot4(D, momw[128 + av * 8 + dq], (uint32_t)s1, false);
             }
         }
+        int m10 = s1 - kHalfPatch * s0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             m10 += __shfl_xor(m10, off);
@@ -163,24 +212,30 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
         // ---- row pass: T[r][j] = sum_c K[c] * R[r][j-3+c], four columns per lane ----
         const uint32_t klo = blurTaps == ORBX_BLUR_CV_4_0_0 ? 0x37312212u : 0x38302212u;  // K0..K3
         const uint32_t khi = blurTaps == ORBX_BLUR_CV_4_0_0 ? 0x00122231u : 0x00122230u;  // K4..K6
-        const uint32_t* R32 = reinterpret_cast<const uint32_t*>(R);
+        int r = lane / kGroups, gq = lane - r * kGroups;      // 64 = 6*10 + 4
 #pragma unroll
         for (int q = 0; q < (kRows * kGroups + 63) / 64; q++) {
-            const int i = lane + 64 * q;
-            if (i >= kRows * kGroups) break;
-            const int r = i / kGroups, gq = i - r * kGroups;
-            const uint32_t A = gq ? R32[r * 12 + gq - 1] : 0u;   // columns 4g-4 .. 4g-1
-            const uint32_t B = R32[r * 12 + gq];                 // columns 4g   .. 4g+3
-            const uint32_t C = R32[r * 12 + gq + 1];             // columns 4g+4 .. 4g+7
-            uint4 o;
-            o.x = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 1), klo,
-                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 1), khi, 0u, false), false);
-            o.y = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 2), klo,
-                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 2), khi, 0u, false), false);
-            o.z = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 3), klo,
-                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 3), khi, 0u, false), false);
-            o.w = __builtin_amdgcn_udot4(B, klo, __builtin_amdgcn_udot4(C, khi, 0u, false), false);
-            *reinterpret_cast<uint4*>(T + r * kTPitch + 4 * gq) = o;
+            if (r < kRows) {
+                const int gg = g0 + gq;
+                const uint32_t A = gg ? R32[r * 12 + gg - 1] : 0u;   // columns 4g-4 .. 4g-1
+                const uint32_t B = R32[r * 12 + gg];                 // columns 4g   .. 4g+3
+                const uint32_t C = R32[r * 12 + gg + 1];             // columns 4g+4 .. 4g+7
+                uint4 o;
+                o.x = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 1), klo,
+                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 1), khi, 0u, false), false);
+                o.y = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 2), klo,
+                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 2), khi, 0u, false), false);
+                o.z = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 3), klo,
+                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 3), khi, 0u, false), false);
+                o.w = __builtin_amdgcn_udot4(B, klo, __builtin_amdgcn_udot4(C, khi, 0u, false), false);
+                *reinterpret_cast<uint4*>(T + r * kTPitch + 4 * gg) = o;
+            }
+            gq += 4;
+            r += 6;
+            if (gq >= kGroups) {
+                gq -= kGroups;
+                r += 1;
+            }
         }
     }
     __syncthreads();
@@ -191,22 +246,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
                        k3 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 55 : 56;
         const uint32_t kk[7] = {k0, k1, k2, k3, k2, k1, k0};
         uint32_t* Bl32 = reinterpret_cast<uint32_t*>(R);
+        int y = lane / kGroups, gq = lane - y * kGroups;
 #pragma unroll
         for (int q = 0; q < (kBlRows * kGroups + 63) / 64; q++) {
-            const int i = lane + 64 * q;
-            if (i >= kBlRows * kGroups) break;
-            const int y = i / kGroups, gq = i - y * kGroups;
-            uint4 acc = make_uint4(32768u, 32768u, 32768u, 32768u);
+            if (y < kBlRows) {
+                const int gg = g0 + gq;
+                uint4 acc = make_uint4(32768u, 32768u, 32768u, 32768u);
 #pragma unroll
-            for (int r = 0; r < 7; r++) {
-                const uint4 t = *reinterpret_cast<const uint4*>(T + (y + r) * kTPitch + 4 * gq);
-                acc.x += kk[r] * t.x;
-                acc.y += kk[r] * t.y;
-                acc.z += kk[r] * t.z;
-                acc.w += kk[r] * t.w;
+                for (int r = 0; r < 7; r++) {
+                    const uint4 t = *reinterpret_cast<const uint4*>(T + (y + r) * kTPitch + 4 * gg);
+                    acc.x += kk[r] * t.x;
+                    acc.y += kk[r] * t.y;
+                    acc.z += kk[r] * t.z;
+                    acc.w += kk[r] * t.w;
+                }
+                Bl32[y * (kTPitch / 4) + gg] = min(acc.x >> 16, 255u) | (min(acc.y >> 16, 255u) << 8) |
+                                               (min(acc.z >> 16, 255u) << 16) | (min(acc.w >> 16, 255u) << 24);
             }
-            Bl32[y * (kTPitch / 4) + gq] = min(acc.x >> 16, 255u) | (min(acc.y >> 16, 255u) << 8) |
-                                           (min(acc.z >> 16, 255u) << 16) | (min(acc.w >> 16, 255u) << 24);
+            gq += 4;
+            y += 6;
+            if (gq >= kGroups) {
+                gq -= kGroups;
+                y += 1;
+            }
         }
     }
     __syncthreads();
