@@ -111,8 +111,10 @@ def hamming_bench(torch, device):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     pairs = nq * ndb / dt
-    # VALU bound: 8 v_xor + 8 v_bcnt per pair; 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz lane-ops/s
-    peak = 256 * 4 * 32 * 2.4e9 / 16
+    # VALU bound: 8 v_xor + 8 v_bcnt per pair. Integer VALU issues one wave64 instruction per SIMD every
+    # 4 cycles (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.0), i.e. 64 lanes/clk/CU:
+    # 256 CUs x 64 lanes x 2.4 GHz = 39.3e12 lane-ops/s, 16 of them per pair.
+    peak = 256 * 64 * 2.4e9 / 16
     assert int((d1[: nq // 2] == 0).sum()) == nq // 2
     return {"metric": "Hamming pairs/s (top-2 kNN, 65536 x 4194304, 1 GPU)", "value": pairs,
             "ms": dt * 1e3, "valu_peak_pairs_per_s": peak, "frac_of_valu_peak": pairs / peak}

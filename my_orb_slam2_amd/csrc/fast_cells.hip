@@ -7,8 +7,8 @@
 // the scanned rectangle as score 0, so no data crosses cells and no score map goes to HBM.
 //
 //   1. the cell's pixels (cell + 6 px) are staged in LDS as coalesced dwords;
-//   2. every scanned pixel runs the cheap antipodal-pair test at the low threshold; survivors are
-//      queued in LDS in row-major order (ballot + prefix count);
+//   2. every scanned pixel runs a cheap antipodal-pair test (two of the eight pairs) at the low
+//      threshold; survivors are queued in LDS in row-major order (ballot + prefix count);
 //   3. queued pixels get the exact corner strength S = max over the 16 arcs of 9 of the smallest
 //      |centre - circle| with one sign; a pixel is a corner at threshold t iff S > t and its FAST
 //      score (cv cornerScore) is S - 1;
@@ -64,12 +64,25 @@ __device__ __forceinline__ int corner_strength(const uint8_t* p) {
 
 // PITCH is the LDS row pitch of the staged cell (bytes, multiple of 4); a compile-time constant so that
 // all sixteen circle offsets fold into the ds_read immediate offsets.
+constexpr int kCellsPerBlock = 4;   // waves per workgroup; every wave works alone on its own cell and LDS slice
+
+// Orders a wave's own LDS traffic: the hardware runs one wave's DS instructions in order, so only the
+// compiler has to be kept from moving accesses across this point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <bool ALIGNED4, int PITCH>
-__global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom g, int iniTh, int minTh) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSet fs, PyramidGeom g, int iniTh,
+                                                                          int minTh, int ldsPerWave) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t* smem = smem_all + wv * ldsPerWave;
     const int f = blockIdx.y;
-    const int cell = blockIdx.x;
+    const int cell = blockIdx.x * kCellsPerBlock + wv;
+    if (cell >= g.totalCells) return;
     int l = 0;
     while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellBase) l++;
     const LevelGeom& L = g.lv[l];
@@ -108,14 +121,35 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
         const int xa = iniX & ~3;
         const int ndw = (maxX - xa + 3) >> 2;
         xo = iniX - xa;
-        const int total = ndw * th;
+        // lane + 64q -> (row, dword) advances without a division; the first eight loads of a lane are
+        // all issued before the first LDS store so their latencies overlap (covers cells up to 12 x 42 dwords)
         const int recip = (65536 + ndw - 1) / ndw;
+        const int dyn = 64 / ndw, dxn = 64 - dyn * ndw;
         uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile);
-        for (int i = lane; i < total; i += 64) {
-            const int y = div_small(i, recip);
-            const int dwi = i - y * ndw;
-            tile32[y * (PITCH / 4) + dwi] =
-                *reinterpret_cast<const uint32_t*>(img + (long long)(iniY + y) * rowStride + xa + dwi * 4);
+        int ty = div_small(lane, recip), td = lane - ty * ndw;
+        const uint8_t* src = img + (long long)(iniY + ty) * rowStride + xa + td * 4;
+        int li = ty * (PITCH / 4) + td;
+        while (ty < th) {                      // wave-uniform trip count is not needed: lanes just idle
+            uint32_t v[8];
+            int idx[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                idx[q] = ty < th ? li : -1;
+                v[q] = ty < th ? *reinterpret_cast<const uint32_t*>(src) : 0u;
+                td += dxn;
+                ty += dyn;
+                src += (long long)dyn * rowStride + dxn * 4;
+                li += dyn * (PITCH / 4) + dxn;
+                if (td >= ndw) {
+                    td -= ndw;
+                    ty += 1;
+                    src += rowStride - ndw * 4;
+                    li += PITCH / 4 - ndw;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (idx[q] >= 0) tile32[idx[q]] = v[q];
         }
     } else {
         const int tw = maxX - iniX;
@@ -135,7 +169,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
         const int ndw = (sp * (sh + 2) + 3) >> 2;
         for (int i = lane; i < ndw; i += 64) s32[i] = 0;
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- 2. cheap test at the low threshold, queue survivors in row-major order ----
     const int npix = sw * sh;
@@ -155,21 +189,11 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
             // circle pixel k and its antipode k+8: a run of 9 holds at least one of each pair
             const int p0 = p[3 * pitch], p8 = p[-3 * pitch];
             const int p4 = p[3], p12 = p[-3];
-            int mnmax = max(min(p0, p8), min(p4, p12));  // all pairs have a pixel < v-t  <=>  this < v-t
-            int mxmin = min(max(p0, p8), max(p4, p12));  // all pairs have a pixel > v+t  <=>  this > v+t
-            if (mnmax < v - tlow || mxmin > v + tlow) {
-                const int p1 = p[3 * pitch + 1], p9 = p[-3 * pitch - 1];
-                const int p2 = p[2 * pitch + 2], p10 = p[-2 * pitch - 2];
-                const int p3 = p[pitch + 3], p11 = p[-pitch - 3];
-                const int p5 = p[-pitch + 3], p13 = p[pitch - 3];
-                const int p6 = p[-2 * pitch + 2], p14 = p[2 * pitch - 2];
-                const int p7 = p[-3 * pitch + 1], p15 = p[3 * pitch - 1];
-                mnmax = max(mnmax, max(max(min(p1, p9), min(p2, p10)), max(min(p3, p11), min(p5, p13))));
-                mnmax = max(mnmax, max(min(p6, p14), min(p7, p15)));
-                mxmin = min(mxmin, min(min(max(p1, p9), max(p2, p10)), min(max(p3, p11), max(p5, p13))));
-                mxmin = min(mxmin, min(max(p6, p14), max(p7, p15)));
-                pass = mnmax < v - tlow || mxmin > v + tlow;
-            }
+            // all pairs have a pixel < v-t  <=>  max over pairs of min < v-t; likewise for > v+t. Two of the
+            // eight pairs reject ~85% of the pixels; what passes goes straight to the exact strength.
+            const int mnmax = max(min(p0, p8), min(p4, p12));
+            const int mxmin = min(max(p0, p8), max(p4, p12));
+            pass = mnmax < v - tlow || mxmin > v + tlow;
         }
         px += dx64;
         addr += dy64 * pitch + dx64;
@@ -181,7 +205,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
         if (pass) queue[nq + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
         nq += __popcll(m);
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- 3. exact corner strength for queued pixels; keep corners (S > tlow) in order ----
     int nc = 0;
@@ -200,7 +224,7 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
         if (S > 0) queue[nc + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
         nc += __popcll(m);
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- 4. suppression + ordered output, iniTh first, minTh if the cell stays empty ----
     int nout = 0;
@@ -241,18 +265,19 @@ __global__ __launch_bounds__(64) void fast_cells_kernel(FrameSet fs, PyramidGeom
 hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nframes, int iniTh, int minTh,
                              hipStream_t s) {
     if (g.totalCells == 0) return hipSuccess;
-    const size_t lds = (size_t)g.maxTileBytes + g.maxScoreBytes + 2 * (size_t)g.maxScanPix + 16;
-    dim3 grid(g.totalCells, nframes, 1), block(64, 1, 1);
+    const int ldsPerWave = (g.maxTileBytes + g.maxScoreBytes + 2 * g.maxScanPix + 16 + 15) & ~15;
+    const size_t lds = (size_t)ldsPerWave * kCellsPerBlock;
+    dim3 grid((g.totalCells + kCellsPerBlock - 1) / kCellsPerBlock, nframes, 1), block(64 * kCellsPerBlock, 1, 1);
     const bool aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
     const bool small = g.tilePitch == 48;
     if (aligned && small)
-        hipLaunchKernelGGL((fast_cells_kernel<true, 48>), grid, block, lds, s, fs, g, iniTh, minTh);
+        hipLaunchKernelGGL((fast_cells_kernel<true, 48>), grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
     else if (aligned)
-        hipLaunchKernelGGL((fast_cells_kernel<true, 80>), grid, block, lds, s, fs, g, iniTh, minTh);
+        hipLaunchKernelGGL((fast_cells_kernel<true, 80>), grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
     else if (small)
-        hipLaunchKernelGGL((fast_cells_kernel<false, 48>), grid, block, lds, s, fs, g, iniTh, minTh);
+        hipLaunchKernelGGL((fast_cells_kernel<false, 48>), grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
     else
-        hipLaunchKernelGGL((fast_cells_kernel<false, 80>), grid, block, lds, s, fs, g, iniTh, minTh);
+        hipLaunchKernelGGL((fast_cells_kernel<false, 80>), grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
     return hipGetLastError();
 }
 
