@@ -80,8 +80,8 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t* smem = smem_all + wv * ldsPerWave;
-    const int f = blockIdx.y;
-    const int cell = blockIdx.x * kCellsPerBlock + wv;
+    const int f = blockIdx.x;                         // frame-fastest grid: one frame per XCD
+    const int cell = blockIdx.y * kCellsPerBlock + wv;
     if (cell >= g.totalCells) return;
     int l = 0;
     while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellBase) l++;
@@ -267,7 +267,7 @@ hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nfram
     if (g.totalCells == 0) return hipSuccess;
     const int ldsPerWave = (g.maxTileBytes + g.maxScoreBytes + 2 * g.maxScanPix + 16 + 15) & ~15;
     const size_t lds = (size_t)ldsPerWave * kCellsPerBlock;
-    dim3 grid((g.totalCells + kCellsPerBlock - 1) / kCellsPerBlock, nframes, 1), block(64 * kCellsPerBlock, 1, 1);
+    dim3 grid(nframes, (g.totalCells + kCellsPerBlock - 1) / kCellsPerBlock, 1), block(64 * kCellsPerBlock, 1, 1);
     const bool aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
     const bool small = g.tilePitch == 48;
     if (aligned && small)

@@ -259,7 +259,7 @@ size_t octree_lds_bytes(const PyramidGeom& g) {
 __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGeom g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int t = threadIdx.x;
-    const int l = blockIdx.x, f = blockIdx.y;
+    const int f = blockIdx.x, l = blockIdx.y;
     const LevelGeom& L = g.lv[l];
     uint32_t* selOut = fs.sel + (long long)f * g.totalSel + L.selBase;
     int32_t* selCountOut = fs.selCount + (long long)f * g.nlevels + l;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
 }
 
 hipError_t launch_octree(const FrameSet& fs, const PyramidGeom& g, int nframes, hipStream_t s) {
-    dim3 grid(g.nlevels, nframes, 1), block(kThreads, 1, 1);
+    dim3 grid(nframes, g.nlevels, 1), block(kThreads, 1, 1);
     const size_t lds = octree_lds_bytes(g);
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it for this kernel
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel),

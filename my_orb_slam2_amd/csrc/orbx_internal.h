@@ -82,6 +82,12 @@ __host__ __device__ inline int cand_x(uint32_t c) { return (int)(c & 0xFFFu); }
 __host__ __device__ inline int cand_y(uint32_t c) { return (int)((c >> 12) & 0xFFFu); }
 __host__ __device__ inline int cand_score(uint32_t c) { return (int)(c >> 24); }
 
+// Grid convention of the batched kernels: blockIdx.x = frame, the tile / cell / keypoint index goes in
+// blockIdx.y (and .z). Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in
+// launch order, x fastest, so with a batch that is a multiple of 8 every block of frame f lands on
+// XCD f % 8: neighbouring cells, patches and source rows of one frame then share one L2 instead of
+// being fetched by up to eight. Pure performance hint; any placement is correct.
+
 // ---- host-side tables (tables.cpp) ----
 struct ScaleTables {
     std::vector<float> scale, invScale, sigma2, invSigma2;

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     __shared__ __attribute__((aligned(16))) uint8_t s_mem[kWavesPerBlock * kWaveLds + kMomLds];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the set-up scalar
-    const int f = blockIdx.y;
-    const int slot = blockIdx.x * kWavesPerBlock + wv;    // index into the frame's selected regions
+    const int f = blockIdx.x;                     // frame-fastest grid: one frame per XCD
+    const int slot = blockIdx.y * kWavesPerBlock + wv;    // index into the frame's selected regions
     uint32_t* momw = reinterpret_cast<uint32_t*>(s_mem + kWavesPerBlock * kWaveLds);
     momw[threadIdx.x] = (&c_momw.w[0][0][0])[threadIdx.x];
     // No wave leaves before the last barrier; inactive waves just skip the work.
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void blur_level_kernel(const uint8_t* __restri
 
 hipError_t launch_orient_desc(const FrameSet& fs, const PyramidGeom& g, int nframes, int blurTaps,
                               orbx_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, hipStream_t s) {
-    dim3 grid((g.totalSel + kWavesPerBlock - 1) / kWavesPerBlock, nframes, 1), block(64 * kWavesPerBlock, 1, 1);
+    dim3 grid(nframes, (g.totalSel + kWavesPerBlock - 1) / kWavesPerBlock, 1), block(64 * kWavesPerBlock, 1, 1);
     const bool aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
     if (aligned)
         hipLaunchKernelGGL(orient_desc_kernel<true>, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts);

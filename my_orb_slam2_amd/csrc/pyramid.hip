@@ -17,9 +17,9 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restri
                                                          int sw, int sh, uint8_t* __restrict__ dstBase,
                                                          long long dstRowStride, long long dstFrameStride,
                                                          int dw, int dh, ResizeTab tab) {
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    const int f = blockIdx.z;
+    const int f = blockIdx.x;
+    const int x4 = (blockIdx.y * 64 + threadIdx.x) * 4;
+    const int dy = blockIdx.z * 4 + threadIdx.y;
     if (x4 >= dw || dy >= dh) return;
     const uint8_t* src = srcBase + (long long)f * srcFrameStride;
     uint8_t* dst = dstBase + (long long)f * dstFrameStride;
@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256) void pyr_resize_dword_kernel(const uint8_t* __
                                                                int sw, int sh, uint8_t* __restrict__ dstBase,
                                                                long long dstRowStride, long long dstFrameStride,
                                                                int dw, int dh, ResizeTab tab) {
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int dy = blockIdx.y * 4 + threadIdx.y;
-    const int f = blockIdx.z;
+    const int f = blockIdx.x;                               // frame-fastest grid: one frame per XCD
+    const int x4 = (blockIdx.y * 64 + threadIdx.x) * 4;
+    const int dy = blockIdx.z * 4 + threadIdx.y;
     if (x4 >= dw || dy >= dh) return;
     const uint8_t* src = srcBase + (long long)f * srcFrameStride;
     uint8_t* dst = dstBase + (long long)f * dstFrameStride;
@@ -114,7 +114,7 @@ hipError_t launch_pyramid(const FrameSet& fs, const PyramidGeom& g, const Resize
             sfs = g.pyrBytes;
         }
         dim3 block(64, 4, 1);
-        dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nframes);
+        dim3 grid(nframes, (D.w + 255) / 256, (D.h + 3) / 4);
         const bool aligned = ((uintptr_t)src % 4 == 0) && (srs % 4 == 0) && (sfs % 4 == 0);
         // 12-byte window: 3 (alignment) + largest step of three columns + 1 neighbour <= 11
         const bool narrow = 3.0 * S.w / D.w + 5.0 <= 11.0;
