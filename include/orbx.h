@@ -180,6 +180,16 @@ int orbx_stereo_band_match_device(orbx_matcher* m, int npairs, int cap,
                                   const orbx_keypoint* d_kr, const uint8_t* d_dr, const int32_t* d_nr,
                                   const float* scale_factors, int nlevels, float bf, float b,
                                   int32_t* d_best_idx, int32_t* d_best_dist, void* stream);
+/* The whole of Frame::ComputeStereoMatches (src/Frame.cc:503-677) for `npairs` stereo pairs: the band
+ * search above, then the 11x11 SAD slide over +-5 px on the pyramid level of the left keypoint, the
+ * parabola fit, disparity / depth (:589-661) and the median-based outlier cut (:663-676). The left and
+ * right images must be frames 0..npairs-1 of the last batched call of `left` and `right` (their
+ * pyramids are read in place; the call waits for those extractions first). d_uright / d_depth receive
+ * mvuRight / mvDepth: cap floats per pair, -1 where a keypoint has no stereo match. */
+int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* left, orbx_ctx* right, int npairs, int cap,
+                                       const orbx_keypoint* d_kl, const uint8_t* d_dl, const int32_t* d_nl,
+                                       const orbx_keypoint* d_kr, const uint8_t* d_dr, const int32_t* d_nr,
+                                       float bf, float b, float* d_uright, float* d_depth, void* stream);
 int orbx_matcher_synchronize(orbx_matcher* m);
 
 /* ---- synthetic frames (host) --------------------------------------------------------------- */

@@ -71,6 +71,8 @@ SIGNATURES = {
     "orbx_ratio_test_device": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int32, C.c_int, C.c_float, _P, _P]),
     "orbx_stereo_band_match_device": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P,
                                                 C.c_int, C.c_float, C.c_float, _P, _P, _P]),
+    "orbx_compute_stereo_matches_device": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P,
+                                                     C.c_float, C.c_float, _P, _P, _P]),
     "orbx_matcher_synchronize": (C.c_int, [_P]),
     "orbx_synth_frame": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _P, C.c_size_t]),

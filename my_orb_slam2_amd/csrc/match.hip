@@ -156,6 +156,146 @@ __global__ __launch_bounds__(256) void stereo_band_kernel(int cap, const orbx_ke
     bestDist[o + iL] = best;
 }
 
+// Second half of Frame::ComputeStereoMatches (src/Frame.cc:589-661): for every left keypoint whose
+// band match is closer than (TH_HIGH + TH_LOW) / 2, slide an 11x11 window +-5 px along the row of the
+// right pyramid level, keep the offset with the smallest sum of absolute differences of the
+// centre-subtracted patches, fit a parabola through its neighbours and turn the sub-pixel column into
+// uRight and depth. One thread per left keypoint. sadDist receives the winning SAD (or -1).
+__global__ __launch_bounds__(256) void stereo_refine_kernel(int cap, PyramidView left, PyramidView right,
+                                                            const orbx_keypoint* __restrict__ kl,
+                                                            const int32_t* __restrict__ nl,
+                                                            const orbx_keypoint* __restrict__ kr,
+                                                            const int32_t* __restrict__ bestIdx,
+                                                            const int32_t* __restrict__ bestDist,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ invScale, float bf, float maxD,
+                                                            float* __restrict__ uRight, float* __restrict__ depth,
+                                                            int32_t* __restrict__ sadDist) {
+    const int pair = blockIdx.y;
+    const int iL = blockIdx.x * 256 + threadIdx.x;
+    if (iL >= cap) return;
+    const long long o = (long long)pair * cap;
+    float outU = -1.0f, outZ = -1.0f;
+    int outD = -1;
+    const int thOrbDist = (100 + 50) / 2;               // (TH_HIGH + TH_LOW) / 2 (:508)
+    if (iL < min(nl[pair], cap) && bestDist[o + iL] < thOrbDist && bestIdx[o + iL] >= 0) {
+        const orbx_keypoint L = kl[o + iL];
+        const int oct = min(max(L.octave, 0), left.nlevels - 1);
+        const float uR0 = kr[o + bestIdx[o + iL]].x;
+        const float sf = invScale[oct];
+        const float scaleduL = roundf(__fmul_rn(L.x, sf)), scaledvL = roundf(__fmul_rn(L.y, sf));
+        const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        const LevelView A = left.lv[oct], B = right.lv[oct];
+        const int w = 5, Lr = 5;
+        const float iniu = scaleduR0 + Lr - w, endu = scaleduR0 + Lr + w + 1;
+        const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
+        // the reference indexes the pyramids unchecked; stay inside both levels
+        const bool inside = cv - w >= 0 && cv + w < A.h && cv + w < B.h && cu - w >= 0 && cu + w < A.w &&
+                            cr - Lr - w >= 0 && cr + Lr + w < B.w;
+        if (!(iniu < 0 || endu >= (float)B.w) && inside) {     // (:612-613)
+            const uint8_t* pa = A.base + (long long)pair * A.frameStride;
+            const uint8_t* pb = B.base + (long long)pair * B.frameStride;
+            const int cL = pa[(long long)cv * A.rowStride + cu];
+            int dists[11];
+            int best = INT32_MAX, bestInc = 0;
+            for (int inc = -Lr; inc <= Lr; inc++) {
+                const int cR = pb[(long long)cv * B.rowStride + cr + inc];
+                int sad = 0;
+                for (int dy = -w; dy <= w; dy++) {
+                    const uint8_t* ra = pa + (long long)(cv + dy) * A.rowStride + cu;
+                    const uint8_t* rb = pb + (long long)(cv + dy) * B.rowStride + cr + inc;
+#pragma unroll
+                    for (int dx = -w; dx <= w; dx++) sad += abs(((int)ra[dx] - cL) - ((int)rb[dx] - cR));
+                }
+                dists[inc + Lr] = sad;
+                if (sad < best) { best = sad; bestInc = inc; }           // float compare of exact integers (:622)
+            }
+            if (bestInc != -Lr && bestInc != Lr) {                      // (:631)
+                float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 11; i++) {                          // no dynamic register indexing
+                    if (i == bestInc + Lr - 1) d1 = (float)dists[i];
+                    if (i == bestInc + Lr) d2 = (float)dists[i];
+                    if (i == bestInc + Lr + 1) d3 = (float)dists[i];
+                }
+                const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
+                                               __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+                if (!(deltaR < -1 || deltaR > 1)) {                      // (:641)
+                    float bestuR = __fmul_rn(scale[oct], __fadd_rn(__fadd_rn(scaleduR0, (float)bestInc), deltaR));
+                    float disparity = __fsub_rn(L.x, bestuR);
+                    if (disparity >= 0 && disparity < maxD) {            // (:649)
+                        if (disparity <= 0) {
+                            disparity = (float)0.01;
+                            bestuR = (float)((double)L.x - 0.01);
+                        }
+                        outZ = __fdiv_rn(bf, disparity);
+                        outU = bestuR;
+                        outD = best;
+                    }
+                }
+            }
+        }
+    }
+    uRight[o + iL] = outU;
+    depth[o + iL] = outZ;
+    sadDist[o + iL] = outD;
+}
+
+// Outlier cut of src/Frame.cc:663-676, one workgroup per pair: median SAD of the accepted matches (the
+// element of rank n/2 in ascending order), threshold 1.5f * 1.4f * median, everything at or above it is
+// reset to -1.
+__global__ __launch_bounds__(256) void stereo_median_cut_kernel(int cap, const int32_t* __restrict__ nl,
+                                                                const int32_t* __restrict__ sadDist,
+                                                                float* __restrict__ uRight, float* __restrict__ depth) {
+    __shared__ int s_cnt[256];
+    const int pair = blockIdx.x, t = threadIdx.x;
+    const long long o = (long long)pair * cap;
+    const int n = min(nl[pair], cap);
+    auto count_le = [&](int v, int& total) {      // #accepted with dist <= v, and #accepted
+        int c = 0, a = 0;
+        for (int i = t; i < n; i += 256) {
+            const int d = sadDist[o + i];
+            a += d >= 0;
+            c += d >= 0 && d <= v;
+        }
+        s_cnt[t] = c;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (t < off) s_cnt[t] += s_cnt[t + off];
+            __syncthreads();
+        }
+        c = s_cnt[0];
+        __syncthreads();
+        s_cnt[t] = a;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (t < off) s_cnt[t] += s_cnt[t + off];
+            __syncthreads();
+        }
+        total = s_cnt[0];
+        __syncthreads();
+        return c;
+    };
+    int total = 0;
+    count_le(0, total);
+    if (total == 0) return;                       // the reference would index an empty vector here
+    const int want = total / 2 + 1;               // smallest v with #(d <= v) >= rank + 1
+    int lo = 0, hi = 121 * 510;                   // largest possible 11x11 SAD of centred bytes
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        int dummy;
+        if (count_le(mid, dummy) >= want) hi = mid; else lo = mid + 1;
+    }
+    const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), (float)lo);
+    for (int i = t; i < n; i += 256) {
+        const int d = sadDist[o + i];
+        if (d >= 0 && !((float)d < thDist)) {
+            uRight[o + i] = -1.0f;
+            depth[o + i] = -1.0f;
+        }
+    }
+}
+
 namespace {
 inline int64_t pick_chunk_rows(int64_t nq, int64_t ndb) {
     // enough (query block x chunk) workgroups to fill 256 CUs several times over
@@ -223,6 +363,20 @@ hipError_t launch_stereo_band(int npairs, int cap, const orbx_keypoint* kl, cons
     dim3 grid((cap + 255) / 256, npairs, 1), block(256, 1, 1);
     hipLaunchKernelGGL(stereo_band_kernel, grid, block, 0, s, cap, kl, reinterpret_cast<const uint4*>(dl), nl,
                        kr, reinterpret_cast<const uint4*>(dr), nr, scale, nlevels, maxD, bestIdx, bestDist);
+    return hipGetLastError();
+}
+
+hipError_t launch_stereo_refine(int npairs, int cap, const PyramidView& left, const PyramidView& right,
+                                const orbx_keypoint* kl, const int32_t* nl, const orbx_keypoint* kr,
+                                const int32_t* bestIdx, const int32_t* bestDist, const float* scale,
+                                const float* invScale, float bf, float maxD, float* uRight, float* depth,
+                                int32_t* sadDist, hipStream_t s) {
+    if (npairs <= 0 || cap <= 0) return hipSuccess;
+    hipLaunchKernelGGL(stereo_refine_kernel, dim3((cap + 255) / 256, npairs, 1), dim3(256), 0, s, cap, left, right,
+                       kl, nl, kr, bestIdx, bestDist, scale, invScale, bf, maxD, uRight, depth, sadDist);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(stereo_median_cut_kernel, dim3(npairs), dim3(256), 0, s, cap, nl, sadDist, uRight, depth);
     return hipGetLastError();
 }
 

@@ -531,7 +531,7 @@ struct orbx_matcher {
     hipStream_t stream = nullptr;
     void* scratch = nullptr;
     size_t scratchBytes = 0;
-    float* scale = nullptr;   // device copy of the scale factors for the stereo search
+    float* scale = nullptr;   // device copy of scale factors [0..15] and inverse scale factors [16..31]
 };
 
 namespace {
@@ -556,7 +556,7 @@ extern "C" int orbx_matcher_create(int device, orbx_matcher** out) {
     if (!m) return ORBX_ERR_INVALID;
     m->device = device;
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->scale), sizeof(float) * ORBX_MAX_LEVELS);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->scale), sizeof(float) * 2 * ORBX_MAX_LEVELS);
     if (e != hipSuccess) {
         set_error("orbx_matcher_create: %s", hipGetErrorString(e));
         orbx_matcher_destroy(m);
@@ -678,5 +678,73 @@ extern "C" int orbx_stereo_band_match_device(orbx_matcher* m, int npairs, int ca
     const float maxD = bf / b;   // mbf / minZ with minZ = mb (src/Frame.cc:533-535)
     HIP_TRY(launch_stereo_band(npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, m->scale, nlevels, maxD,
                                d_best_idx, d_best_dist, s));
+    return ORBX_OK;
+}
+
+namespace {
+void pyramid_view(const orbx_ctx* c, PyramidView& v) {
+    const PyramidGeom& g = c->geom;
+    v.nlevels = g.nlevels;
+    for (int l = 0; l < g.nlevels; l++) {
+        LevelView& L = v.lv[l];
+        L.w = g.lv[l].w;
+        L.h = g.lv[l].h;
+        if (l == 0) {
+            L.base = c->fs.img;
+            L.rowStride = c->fs.imgRowStride;
+            L.frameStride = c->fs.imgFrameStride;
+        } else {
+            L.base = c->fs.pyr + g.lv[l].offset;
+            L.rowStride = g.lv[l].stride;
+            L.frameStride = g.pyrBytes;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* left, orbx_ctx* right, int npairs,
+                                                  int cap, const orbx_keypoint* d_kl, const uint8_t* d_dl,
+                                                  const int32_t* d_nl, const orbx_keypoint* d_kr,
+                                                  const uint8_t* d_dr, const int32_t* d_nr, float bf, float b,
+                                                  float* d_uright, float* d_depth, void* stream) {
+    if (!m || !left || !right || npairs < 0 || cap < 1 || !(b > 0) ||
+        (npairs > 0 && (!d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_uright || !d_depth)) ||
+        ((uintptr_t)d_dl % 16) || ((uintptr_t)d_dr % 16)) {
+        set_error("orbx_compute_stereo_matches_device: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (npairs == 0) return ORBX_OK;
+    if (!left->haveGeom || !right->haveGeom || npairs > left->lastFrames || npairs > right->lastFrames ||
+        left->cfg.nlevels != right->cfg.nlevels || left->cfg.device != m->device || right->cfg.device != m->device ||
+        left->geom.width != right->geom.width || left->geom.height != right->geom.height) {
+        set_error("orbx_compute_stereo_matches_device: the two contexts do not hold %d matching frames", npairs);
+        return ORBX_ERR_STATE;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+    if (left->lastStream != s) HIP_TRY(hipStreamSynchronize(left->lastStream));
+    if (right->lastStream != s) HIP_TRY(hipStreamSynchronize(right->lastStream));
+    const size_t n = (size_t)npairs * cap;
+    int rc = matcher_scratch(m, n * 3 * sizeof(int32_t), s);
+    if (rc) return rc;
+    int32_t* bestIdx = static_cast<int32_t*>(m->scratch);
+    int32_t* bestDist = bestIdx + n;
+    int32_t* sad = bestDist + n;
+    const int nl = left->cfg.nlevels;
+    float host[2 * ORBX_MAX_LEVELS] = {0};
+    for (int l = 0; l < nl; l++) {
+        host[l] = left->tab.scale[l];
+        host[ORBX_MAX_LEVELS + l] = left->tab.invScale[l];
+    }
+    HIP_TRY(hipMemcpyAsync(m->scale, host, sizeof(host), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));   // `host` is a stack buffer
+    const float maxD = bf / b;          // mbf / minZ with minZ = mb (src/Frame.cc:533-535)
+    HIP_TRY(launch_stereo_band(npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, m->scale, nl, maxD, bestIdx,
+                               bestDist, s));
+    PyramidView lv, rv;
+    pyramid_view(left, lv);
+    pyramid_view(right, rv);
+    HIP_TRY(launch_stereo_refine(npairs, cap, lv, rv, d_kl, d_nl, d_kr, bestIdx, bestDist, m->scale,
+                                 m->scale + ORBX_MAX_LEVELS, bf, maxD, d_uright, d_depth, sad, s));
     return ORBX_OK;
 }

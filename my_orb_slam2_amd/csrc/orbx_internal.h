@@ -103,6 +103,18 @@ struct HostResizeTab {
 };
 void build_resize_table(int sw, int sh, int dw, int dh, HostResizeTab& t);
 
+// Where the levels of the frames of a context's last batched call live (for kernels that read the
+// pyramids of two contexts, e.g. the stereo refinement).
+struct LevelView {
+    const uint8_t* base;            // level pixel (0,0) of frame 0
+    long long rowStride, frameStride;
+    int w, h;
+};
+struct PyramidView {
+    int nlevels;
+    LevelView lv[ORBX_MAX_LEVELS];
+};
+
 // ---- error plumbing ----
 void set_error(const char* fmt, ...);
 
@@ -131,5 +143,11 @@ hipError_t launch_stereo_band(int npairs, int cap, const orbx_keypoint* kl, cons
                               const int32_t* nl, const orbx_keypoint* kr, const uint8_t* dr,
                               const int32_t* nr, const float* scale, int nlevels, float maxD,
                               int32_t* bestIdx, int32_t* bestDist, hipStream_t s);
+
+hipError_t launch_stereo_refine(int npairs, int cap, const PyramidView& left, const PyramidView& right,
+                                const orbx_keypoint* kl, const int32_t* nl, const orbx_keypoint* kr,
+                                const int32_t* bestIdx, const int32_t* bestDist, const float* scale,
+                                const float* invScale, float bf, float maxD, float* uRight, float* depth,
+                                int32_t* sadDist, hipStream_t s);
 
 }  // namespace orbx

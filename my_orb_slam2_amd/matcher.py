@@ -96,5 +96,17 @@ class HammingMatcher:
             C.c_void_p(d_best_idx.data_ptr()), C.c_void_p(d_best_dist.data_ptr()), sp),
             "orbx_stereo_band_match_device")
 
+    def compute_stereo_matches_device(self, left, right, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, bf, b,
+                                      d_uright, d_depth, stream=None):
+        """Frame::ComputeStereoMatches (src/Frame.cc:503-677) for the stereo pairs that `left` and `right`
+        (two ORBextractor objects) extracted in their last batched call. Fills mvuRight / mvDepth."""
+        npairs, cap = d_dl.shape[0], d_dl.shape[1]
+        sp = C.c_void_p(stream) if stream else None
+        check(lib().orbx_compute_stereo_matches_device(
+            self._m, left._ctx, right._ctx, npairs, cap, C.c_void_p(d_kl.data_ptr()), C.c_void_p(d_dl.data_ptr()),
+            C.c_void_p(d_nl.data_ptr()), C.c_void_p(d_kr.data_ptr()), C.c_void_p(d_dr.data_ptr()),
+            C.c_void_p(d_nr.data_ptr()), float(bf), float(b), C.c_void_p(d_uright.data_ptr()),
+            C.c_void_p(d_depth.data_ptr()), sp), "orbx_compute_stereo_matches_device")
+
     def synchronize(self):
         check(lib().orbx_matcher_synchronize(self._m), "orbx_matcher_synchronize")

@@ -822,3 +822,85 @@ extern "C" int orc_stereo_band_match(const orc_keypoint* kl, const uint8_t* dl, 
     }
     return 0;
 }
+
+/* Frame::ComputeStereoMatches (src/Frame.cc:503-677) */
+extern "C" int orc_compute_stereo_matches(const orc_extractor* left, const orc_extractor* right,
+                                          const orc_keypoint* kl, const uint8_t* dl, int nl,
+                                          const orc_keypoint* kr, const uint8_t* dr, int nr, float bf, float b,
+                                          float* uright, float* depth) {
+    if (!left || !right || left->padded.empty() || right->padded.empty()) return -1;
+    const int TH_HIGH = 100, TH_LOW = 50;
+    for (int i = 0; i < nl; i++) uright[i] = depth[i] = -1.0f;
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = left->lh[0];
+    std::vector<int32_t> bi(nl), bd(nl);
+    if (orc_stereo_band_match(kl, dl, nl, kr, dr, nr, nRows, left->scale.data(), left->nlevels, bf, b,
+                              bi.data(), bd.data()) != 0)
+        return -1;
+    const float minD = 0, maxD = bf / b;
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int iL = 0; iL < nl; iL++) {
+        if (!(bd[iL] < thOrbDist) || bi[iL] < 0) continue;
+        const orc_keypoint& kpL = kl[iL];
+        const float uL = kpL.x;
+        const float uR0 = kr[bi[iL]].x;
+        const float scaleFactor = left->inv_scale[kpL.octave];
+        const float scaleduL = std::round(kpL.x * scaleFactor);
+        const float scaledvL = std::round(kpL.y * scaleFactor);
+        const float scaleduR0 = std::round(uR0 * scaleFactor);
+        const int w = 5, L = 5;
+        const Image& PL = left->padded[kpL.octave];
+        const Image& PR = right->padded[kpL.octave];
+        const int colsR = right->lw[kpL.octave];
+        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+        if (iniu < 0 || endu >= colsR) continue;
+        auto at = [&](const Image& P, int y, int x) { return (float)P.row(y + kEdge)[x + kEdge]; };
+        const int cv = (int)scaledvL, cu = (int)scaleduL, cr = (int)scaleduR0;
+        float IL[11][11];
+        const float cL = at(PL, cv, cu);
+        for (int dy = -w; dy <= w; dy++)
+            for (int dx = -w; dx <= w; dx++) IL[dy + w][dx + w] = at(PL, cv + dy, cu + dx) - cL;
+        int bestDist = INT_MAX, bestincR = 0;
+        std::vector<float> vDists(2 * L + 1);
+        for (int incR = -L; incR <= +L; incR++) {
+            const float cR = at(PR, cv, cr + incR);
+            double acc = 0; /* cv::norm(NORM_L1) on CV_32F accumulates in double; the terms are integers */
+            for (int dy = -w; dy <= w; dy++)
+                for (int dx = -w; dx <= w; dx++)
+                    acc += std::fabs(IL[dy + w][dx + w] - (at(PR, cv + dy, cr + incR + dx) - cR));
+            const float dist = (float)acc;
+            if (dist < bestDist) {
+                bestDist = (int)dist;
+                bestincR = incR;
+            }
+            vDists[L + incR] = dist;
+        }
+        if (bestincR == -L || bestincR == L) continue;
+        const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+        const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+        if (deltaR < -1 || deltaR > 1) continue;
+        float bestuR = left->scale[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+        float disparity = (uL - bestuR);
+        if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) {
+                disparity = 0.01;
+                bestuR = uL - 0.01;
+            }
+            depth[iL] = bf / disparity;
+            uright[iL] = bestuR;
+            vDistIdx.push_back(std::pair<int, int>(bestDist, iL));
+        }
+    }
+    if (vDistIdx.empty()) return 0; /* the reference indexes the empty vector here */
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    int kept = (int)vDistIdx.size();
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        uright[vDistIdx[i].second] = -1;
+        depth[vDistIdx[i].second] = -1;
+        kept--;
+    }
+    return kept;
+}

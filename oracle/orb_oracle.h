@@ -100,6 +100,15 @@ int   orc_stereo_band_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
                             int rows, const float* scale, int nlevels, float bf, float b,
                             int32_t* best_idx, int32_t* best_dist);
 
+/* The whole of Frame::ComputeStereoMatches (src/Frame.cc:503-677): band search, SAD slide on the
+ * pyramids that `left` / `right` kept from their last orc_extract() call, parabola fit, depth, and the
+ * median-based outlier cut. uright / depth receive mvuRight / mvDepth (nl floats, -1 = no match).
+ * Returns the number of matches kept, or -1 where the reference would read out of bounds. */
+int   orc_compute_stereo_matches(const orc_extractor* left, const orc_extractor* right,
+                                 const orc_keypoint* kl, const uint8_t* dl, int nl,
+                                 const orc_keypoint* kr, const uint8_t* dr, int nr,
+                                 float bf, float b, float* uright, float* depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,8 @@ def lib():
         L.orc_stereo_band_match.restype = C.c_int
         L.orc_stereo_band_match.argtypes = [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P, C.c_int,
                                             C.c_float, C.c_float, _P, _P]
+        L.orc_compute_stereo_matches.restype = C.c_int
+        L.orc_compute_stereo_matches.argtypes = [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P]
         _LIB = L
     return _LIB
 
@@ -205,3 +207,17 @@ def stereo_band_match(kl, dl, kr, dr, rows, scale, bf, b):
                                      len(scale), bf, b, ptr(bi), ptr(bd))
     assert rc == 0
     return bi, bd
+
+
+def compute_stereo_matches(ex_left, ex_right, kl, dl, kr, dr, bf, b):
+    """ex_left / ex_right: oracle Extractor objects that just extracted the two images."""
+    kl = np.ascontiguousarray(kl, dtype=KP)
+    kr = np.ascontiguousarray(kr, dtype=KP)
+    dl = np.ascontiguousarray(dl, dtype=np.uint8)
+    dr = np.ascontiguousarray(dr, dtype=np.uint8)
+    ur = np.empty(len(kl), dtype=np.float32)
+    z = np.empty(len(kl), dtype=np.float32)
+    kept = lib().orc_compute_stereo_matches(ex_left.h, ex_right.h, ptr(kl), ptr(dl), len(kl), ptr(kr), ptr(dr), len(kr),
+                                            bf, b, ptr(ur), ptr(z))
+    assert kept >= 0
+    return ur, z, kept

@@ -118,3 +118,44 @@ def test_stereo_band_match_on_extracted_pairs():
         assert np.array_equal(bi[p, :nl[p]], oi) and np.array_equal(bd[p, :nl[p]], od)
         matched += int((od < 75).sum())
     assert matched > 300
+
+
+def test_compute_stereo_matches_full():
+    """Band search + SAD refinement + median cut against the oracle's Frame::ComputeStereoMatches."""
+    import torch
+    npairs = 4
+    ex_l = m.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=npairs)
+    ex_r = m.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=npairs)
+    cap = ex_l.capacity
+    left = np.stack([m.synth_frame(60 + p) for p in range(npairs)])
+    right = np.stack([m.synth_frame(60 + p, right_view=True) for p in range(npairs)])
+    d_left, d_right = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+
+    def alloc():
+        return (torch.zeros((npairs, cap, 7), dtype=torch.float32, device="cuda"),
+                torch.zeros((npairs, cap, 32), dtype=torch.uint8, device="cuda"),
+                torch.zeros(npairs, dtype=torch.int32, device="cuda"))
+    kl, dl, nl = alloc()
+    kr, dr, nr = alloc()
+    ex_l.extract_batch_device(d_left, kl, dl, nl)
+    ex_r.extract_batch_device(d_right, kr, dr, nr)
+    bf, b = 47.90639384423901, 47.90639384423901 / 435.2046959714599
+    ur = torch.empty((npairs, cap), dtype=torch.float32, device="cuda")
+    z = torch.empty((npairs, cap), dtype=torch.float32, device="cuda")
+    hm = m.HammingMatcher()
+    hm.compute_stereo_matches_device(ex_l, ex_r, kl, dl, nl, kr, dr, nr, bf, b, ur, z)
+    hm.synchronize()
+    ur, z = ur.cpu().numpy(), z.cpu().numpy()
+    nl = nl.cpu().numpy()
+    total = 0
+    for p in range(npairs):
+        ol, orr = orc.Extractor(1200), orc.Extractor(1200)
+        okl, odl = ol.extract(left[p])
+        okr, odr = orr.extract(right[p])
+        assert nl[p] == len(okl)
+        our, oz, kept = orc.compute_stereo_matches(ol, orr, okl, odl, okr, odr, bf, b)
+        assert np.array_equal(ur[p, :nl[p]], our), "uRight differs in pair %d" % p
+        assert np.array_equal(z[p, :nl[p]], oz), "depth differs in pair %d" % p
+        assert kept == int((our >= 0).sum())
+        total += kept
+    assert total > 400
