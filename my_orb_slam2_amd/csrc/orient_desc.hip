@@ -9,9 +9,10 @@
 // filter (u16 row sums, 16.16 column sums, one rounding at the end: cv fixedSmoothInvoker), and
 // samples the blurred patch. No blurred level is ever written to HBM.
 //   R  raw bytes, 43 rows x 48 B, columns aligned to a dword of the image row (coalesced dword loads)
-//   T  row sums as u32, 43 x 44: four outputs per lane from three dwords via v_alignbyte + v_dot4_u32_u8
-//   Bl blurred bytes, 37 x 44 (overlays R once the row pass is done): four outputs per lane from
-//      seven 16-byte reads and v_mad_u32_u24
+//   T  row sums as u16 (they never exceed 257*255), rows 2j and 2j+1 packed into one dword per column,
+//      22 x 44 dwords: four outputs per lane from three raw dwords via v_alignbyte + v_dot4_u32_u8
+//   Bl blurred bytes, 37 x 44 (overlays R once the row pass is done): four outputs per lane, each from
+//      four v_dot2_u32_u16 over the packed row pairs (the 7 taps straddle 4 pairs either way round)
 // orbx_debug_blur_level() runs the same arithmetic over a full level for parity tests.
 #include "orbx_internal.h"
 
@@ -54,11 +55,12 @@ __device__ const MomentWeights c_momw = make_moment_weights();
 constexpr int kPR = 21;                 // patch radius
 constexpr int kRows = 2 * kPR + 1;      // 43 patch rows
 constexpr int kRPitch = 48;             // bytes per raw row (12 dwords)
-constexpr int kTPitch = 44;             // u32 per row of T, bytes per row of Bl
+constexpr int kTPitch = 44;             // dwords per packed row pair of T, bytes per row of Bl
+constexpr int kTPairs = 22;             // row pairs of T (43 rows)
 constexpr int kGroups = 10;             // 4-column groups blurred per row (40 columns cover cx-18..cx+18)
 constexpr int kBlRows = 37;             // blurred rows: patch rows 3..39
 constexpr int kWavesPerBlock = 4;
-constexpr int kWaveLds = kRows * kRPitch + kRows * kTPitch * 4;   // 2064 + 7568 bytes
+constexpr int kWaveLds = kRows * kRPitch + kTPairs * kTPitch * 4;  // 2064 + 3872 bytes
 constexpr int kMomLds = 2 * 16 * 8 * 4;                             // moment weights, shared by the block
 
 __device__ __forceinline__ int reflect101(int p, int len) {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     }
     const LevelGeom& L = g.lv[l];
     uint8_t* R = s_mem + wv * kWaveLds;                                   // raw patch, later Bl
-    uint32_t* T = reinterpret_cast<uint32_t*>(R + kRows * kRPitch);      // row sums
+    uint32_t* T = reinterpret_cast<uint32_t*>(R + kRows * kRPitch);      // packed row sums
     if (active) {
         packed = fs.sel[(long long)f * g.totalSel + slot];
         kx = cand_x(packed) + kBorder;   // level coordinates (:835-836)
@@ -228,7 +230,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
                 o.z = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 3), klo,
                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 3), khi, 0u, false), false);
                 o.w = __builtin_amdgcn_udot4(B, klo, __builtin_amdgcn_udot4(C, khi, 0u, false), false);
-                *reinterpret_cast<uint4*>(T + r * kTPitch + 4 * gg) = o;
+                // row r is the low (even r) or high (odd r) half of pair r/2
+                uint16_t* t16 = reinterpret_cast<uint16_t*>(T + (r >> 1) * kTPitch + 4 * gg) + (r & 1);
+                t16[0] = (uint16_t)o.x;
+                t16[2] = (uint16_t)o.y;
+                t16[4] = (uint16_t)o.z;
+                t16[6] = (uint16_t)o.w;
             }
             gq += 4;
             r += 6;
@@ -242,9 +249,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
 
     // ---- column pass: Bl[y][j] = min(255, (sum_r K[r] * T[y+r][j] + 32768) >> 16), y = patch row - 3 ----
     if (active) {
-        const uint32_t k0 = 18, k1 = 34, k2 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 49 : 48,
-                       k3 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 55 : 56;
-        const uint32_t kk[7] = {k0, k1, k2, k3, k2, k1, k0};
+        // taps as u16 pairs. Blurred row y uses patch rows y..y+6; for even y those are the pairs
+        // (y,y+1)(y+2,y+3)(y+4,y+5)(y+6,-), for odd y (-,y)(y+1,y+2)(y+3,y+4)(y+5,y+6).
+        const uint32_t k2 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 49u : 48u, k3 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 55u : 56u;
+        const uint32_t we[4] = {18u | (34u << 16), k2 | (k3 << 16), k2 | (34u << 16), 18u};
+        const uint32_t wo[4] = {18u << 16, 34u | (k2 << 16), k3 | (k2 << 16), 34u | (18u << 16)};
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         uint32_t* Bl32 = reinterpret_cast<uint32_t*>(R);
         int y = lane / kGroups, gq = lane - y * kGroups;
 #pragma unroll
@@ -252,13 +262,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
             if (y < kBlRows) {
                 const int gg = g0 + gq;
                 uint4 acc = make_uint4(32768u, 32768u, 32768u, 32768u);
+                const bool odd = y & 1;
+                const uint32_t* tp = T + (y >> 1) * kTPitch + 4 * gg;
 #pragma unroll
-                for (int r = 0; r < 7; r++) {
-                    const uint4 t = *reinterpret_cast<const uint4*>(T + (y + r) * kTPitch + 4 * gg);
-                    acc.x += kk[r] * t.x;
-                    acc.y += kk[r] * t.y;
-                    acc.z += kk[r] * t.z;
-                    acc.w += kk[r] * t.w;
+                for (int r = 0; r < 4; r++) {
+                    const uint4 t = *reinterpret_cast<const uint4*>(tp + r * kTPitch);
+                    const us2 w = __builtin_bit_cast(us2, odd ? wo[r] : we[r]);
+                    acc.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), w, acc.x, false);
+                    acc.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), w, acc.y, false);
+                    acc.z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.z), w, acc.z, false);
+                    acc.w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.w), w, acc.w, false);
                 }
                 Bl32[y * (kTPitch / 4) + gg] = min(acc.x >> 16, 255u) | (min(acc.y >> 16, 255u) << 8) |
                                                (min(acc.z >> 16, 255u) << 16) | (min(acc.w >> 16, 255u) << 24);
