@@ -100,15 +100,23 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
         c->resize[l].ialpha = reinterpret_cast<const int16_t*>(put(ht[l].ialpha.data(), ht[l].ialpha.size() * 2));
         c->resize[l].ibeta = reinterpret_cast<const int16_t*>(put(ht[l].ibeta.data(), ht[l].ibeta.size() * 2));
         c->resize[l].xmax = ht[l].xmax;
-        // packed per-column records, padded to a multiple of four with copies of the last column
+        // packed per-column records, padded to a multiple of four with copies of the last column. The
+        // first column of every group of four carries its source column; the others carry the v_perm_b32
+        // selector that picks bytes d and d+1 (d = their source column minus the group's first) out of an
+        // 8-byte window into the low and high 16-bit halves (0x0c = constant zero byte).
         const size_t n = ht[l].xofs.size(), n4 = (n + 3) / 4 * 4;
         std::vector<int32_t> xe(2 * n4);
+        int maxSpan = 0;
         for (size_t i = 0; i < n4; i++) {
-            const size_t j = std::min(i, n - 1);
-            xe[2 * i] = ht[l].xofs[j];
+            const size_t j = std::min(i, n - 1), j0 = std::min(i & ~(size_t)3, n - 1);
+            const int d = ht[l].xofs[j] - ht[l].xofs[j0];
+            maxSpan = std::max(maxSpan, d);
+            const uint32_t dd = (uint32_t)std::min(std::max(d, 0), 6);
+            xe[2 * i] = (i & 3) == 0 ? ht[l].xofs[j] : (int32_t)(0x0c000c00u | dd | ((dd + 1) << 16));
             xe[2 * i + 1] = (int32_t)((uint32_t)(uint16_t)ht[l].ialpha[2 * j] |
                                       ((uint32_t)(uint16_t)ht[l].ialpha[2 * j + 1] << 16));
         }
+        c->resize[l].maxSpan = maxSpan;
         c->resize[l].xentry = reinterpret_cast<const int32_t*>(put(xe.data(), xe.size() * 4));
     }
     HIP_TRY(hipMemcpy(c->resizeBlob, blob.data(), blob.size(), hipMemcpyHostToDevice));

@@ -67,7 +67,8 @@ struct FrameSet {
 // Bilinear resize tables of one level (cv::resize INTER_LINEAR, 8U fixed point).
 struct ResizeTab {
     const int32_t* xofs;    // [dw]
-    const int32_t* xentry;  // [dw rounded up to 4][2]: {xofs, ialpha0 | ialpha1 << 16}
+    const int32_t* xentry;  // [dw rounded up to 4][2]: {xofs (column % 4 == 0) or v_perm selector, ialpha0 | ialpha1 << 16}
+    int maxSpan;            // largest xofs[4g + k] - xofs[4g] over all groups of four columns
     const int16_t* ialpha;  // [dw][2]
     const int32_t* yofs;    // [dh]
     const int16_t* ibeta;   // [dh][2]

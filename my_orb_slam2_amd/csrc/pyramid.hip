@@ -45,55 +45,84 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restri
     *reinterpret_cast<uint32_t*>(dst + (long long)dy * dstRowStride + x4) = packed;
 }
 
-// Fast path: same arithmetic, far fewer memory instructions. The four source spans a thread needs
-// lie within 12 bytes of (sx[first] & ~3), so each source row costs three aligned dword loads and the
-// neighbouring byte pairs are cut out with v_alignbyte; the per-column table entry {sx, a0, a1} is
-// one 8-byte record, 32 contiguous bytes per thread. Needs 4-byte aligned rows and a
-// source/destination ratio small enough for the 12-byte window.
+// Fast path: same arithmetic, far fewer instructions. A thread makes four destination pixels per row for
+// kRowsPerThread consecutive rows; a wave (threadIdx.y) owns whole rows, so everything that depends only
+// on the row is scalar. Per source row: three aligned dword loads (the 12 bytes around the first source
+// column), two v_alignbyte to bring that column to byte 0 of an 8-byte window, and per pixel one
+// v_perm_b32 that puts S[sx], S[sx+1] into the two 16-bit halves plus one v_dot2_i32_i16 with the
+// packed weights (a0, a1). Consecutive destination rows share a source row most of the time (the lower
+// row of one is the upper row of the next); its horizontal sums are kept in registers. The per-column
+// table record is 8 bytes, {sx for the first column of a group of four, else the v_perm selector;
+// a0 | a1 << 16}, built on the host and loaded once per thread. Needs 4-byte aligned rows and a
+// source/destination ratio <= 2.
+constexpr int kRowsPerThread = 8;
+
 __global__ __launch_bounds__(256) void pyr_resize_dword_kernel(const uint8_t* __restrict__ srcBase,
                                                                long long srcRowStride, long long srcFrameStride,
                                                                int sw, int sh, uint8_t* __restrict__ dstBase,
                                                                long long dstRowStride, long long dstFrameStride,
                                                                int dw, int dh, ResizeTab tab) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
     const int f = blockIdx.x;                               // frame-fastest grid: one frame per XCD
     const int x4 = (blockIdx.y * 64 + threadIdx.x) * 4;
-    const int dy = blockIdx.z * 4 + threadIdx.y;
-    if (x4 >= dw || dy >= dh) return;
+    const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int dyBegin = (blockIdx.z * 4 + wy) * kRowsPerThread;
+    if (x4 >= dw || dyBegin >= dh) return;
     const uint8_t* src = srcBase + (long long)f * srcFrameStride;
-    uint8_t* dst = dstBase + (long long)f * dstFrameStride;
-    int sy0 = tab.yofs[dy], sy1 = sy0 + 1;
-    sy0 = min(max(sy0, 0), sh - 1);
-    sy1 = min(max(sy1, 0), sh - 1);
-    const int b0 = tab.ibeta[2 * dy], b1 = tab.ibeta[2 * dy + 1];
-    // the table is padded to a multiple of four entries
+    uint8_t* dst = dstBase + (long long)f * dstFrameStride + x4;
+    // the table is padded to a multiple of four columns
     const uint4* xe = reinterpret_cast<const uint4*>(tab.xentry + 2 * x4);
     const uint4 e01 = xe[0], e23 = xe[1];
-    const int sx[4] = {(int)e01.x, (int)e01.z, (int)e23.x, (int)e23.z};
+    const int sx0 = (int)e01.x;
+    const uint32_t sel[4] = {0x0c010c00u, e01.z, e23.x, e23.z};
     const uint32_t aa[4] = {e01.y, e01.w, e23.y, e23.w};
-    const int c0 = sx[0] & ~3;
     const int lastDw = ((sw + 3) >> 2) - 1;
-    const int q0 = c0 >> 2;
-    const uint32_t* R0 = reinterpret_cast<const uint32_t*>(src + (long long)sy0 * srcRowStride);
-    const uint32_t* R1 = reinterpret_cast<const uint32_t*>(src + (long long)sy1 * srcRowStride);
+    const int q0 = sx0 >> 2;
+    const uint32_t sh8 = (uint32_t)(sx0 & 3);
     const int i0 = min(q0, lastDw), i1 = min(q0 + 1, lastDw), i2 = min(q0 + 2, lastDw);
-    const uint32_t u0 = R0[i0], u1 = R0[i1], u2 = R0[i2];
-    const uint32_t v0 = R1[i0], v1 = R1[i1], v2 = R1[i2];
-    uint32_t packed = 0;
+
+    // horizontal pass of one source row for this thread's four columns
+    auto hrow = [&](int sy, int (&h)[4]) {
+        const uint32_t* R = reinterpret_cast<const uint32_t*>(src + (long long)sy * srcRowStride);
+        const uint32_t u0 = R[i0], u1 = R[i1], u2 = R[i2];
+        // 8-byte window starting at source column sx0 (bytes past the row end only meet zero weights)
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(u1, u0, sh8), w1 = __builtin_amdgcn_alignbyte(u2, u1, sh8);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int o = sx[k] - c0;          // 0..10
-        const int q = o >> 2;
-        const uint32_t ulo = q == 0 ? u0 : (q == 1 ? u1 : u2), uhi = q == 0 ? u1 : u2;
-        const uint32_t vlo = q == 0 ? v0 : (q == 1 ? v1 : v2), vhi = q == 0 ? v1 : v2;
-        const uint32_t pu = __builtin_amdgcn_alignbyte(uhi, ulo, (uint32_t)(o & 3));   // S0[sx], S0[sx+1] in bytes 0,1
-        const uint32_t pv = __builtin_amdgcn_alignbyte(vhi, vlo, (uint32_t)(o & 3));
-        const int a0 = (int)(int16_t)(aa[k] & 0xFFFFu), a1 = (int)(int16_t)(aa[k] >> 16);
-        const int h0 = (int)(pu & 0xFFu) * a0 + (int)((pu >> 8) & 0xFFu) * a1;
-        const int h1 = (int)(pv & 0xFFu) * a0 + (int)((pv >> 8) & 0xFFu) * a1;
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        packed |= (uint32_t)min(max(v, 0), 255) << (8 * k);
+        for (int k = 0; k < 4; k++)
+            h[k] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, __builtin_amdgcn_perm(w1, w0, sel[k])),
+                                          __builtin_bit_cast(s2, aa[k]), 0, false);
+    };
+
+    int cachedSy = -1;       // source row whose sums sit in hb
+    int ha[4], hb[4] = {0, 0, 0, 0};
+    const int dyEnd = min(dyBegin + kRowsPerThread, dh);
+    for (int dy = dyBegin; dy < dyEnd; dy++) {
+        int sy0 = tab.yofs[dy], sy1 = sy0 + 1;
+        sy0 = min(max(sy0, 0), sh - 1);
+        sy1 = min(max(sy1, 0), sh - 1);
+        const int b0 = tab.ibeta[2 * dy], b1 = tab.ibeta[2 * dy + 1];
+        if (sy0 == cachedSy) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) ha[k] = hb[k];
+        } else {
+            hrow(sy0, ha);
+        }
+        if (sy1 != sy0) {
+            hrow(sy1, hb);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) hb[k] = ha[k];
+        }
+        cachedSy = sy1;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // never leaves [0, 255]: the weights are non-negative and a0 + a1, b0 + b1 <= 2049
+            const int v = (((b0 * (ha[k] >> 4)) >> 16) + ((b1 * (hb[k] >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)v << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(dst + (long long)dy * dstRowStride) = packed;
     }
-    *reinterpret_cast<uint32_t*>(dst + (long long)dy * dstRowStride + x4) = packed;
 }
 
 hipError_t launch_pyramid(const FrameSet& fs, const PyramidGeom& g, const ResizeTab* tabs, int nframes,
@@ -116,10 +145,12 @@ hipError_t launch_pyramid(const FrameSet& fs, const PyramidGeom& g, const Resize
         dim3 block(64, 4, 1);
         dim3 grid(nframes, (D.w + 255) / 256, (D.h + 3) / 4);
         const bool aligned = ((uintptr_t)src % 4 == 0) && (srs % 4 == 0) && (sfs % 4 == 0);
-        // 12-byte window: 3 (alignment) + largest step of three columns + 1 neighbour <= 11
-        const bool narrow = 3.0 * S.w / D.w + 5.0 <= 11.0;
+        // 8-byte window from the first source column: three column steps + 1 neighbour must stay <= 7
+        const bool narrow = tabs[l].maxSpan <= 6;
         if (aligned && narrow)
-            hipLaunchKernelGGL(pyr_resize_dword_kernel, grid, block, 0, s, src, srs, sfs, S.w, S.h,
+            hipLaunchKernelGGL(pyr_resize_dword_kernel,
+                               dim3(nframes, (D.w + 255) / 256, (D.h + 4 * kRowsPerThread - 1) / (4 * kRowsPerThread)),
+                               block, 0, s, src, srs, sfs, S.w, S.h,
                                fs.pyr + D.offset, (long long)D.stride, g.pyrBytes, D.w, D.h, tabs[l]);
         else
             hipLaunchKernelGGL(pyr_resize_kernel, grid, block, 0, s, src, srs, sfs, S.w, S.h,
