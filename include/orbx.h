@@ -192,6 +192,34 @@ int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* left, orbx_ctx
                                        float bf, float b, float* d_uright, float* d_depth, void* stream);
 int orbx_matcher_synchronize(orbx_matcher* m);
 
+/* ---- the step after extraction: undistort + grid ---------------------------------------------- */
+
+/* Camera.fx/fy/cx/cy and Camera.k1/k2/p1/p2/k3 as Tracking reads them (src/Tracking.cc:51-79) into
+ * mK and mDistCoef. */
+typedef struct orbx_camera {
+    float fx, fy, cx, cy;
+    float k1, k2, p1, p2, k3;
+} orbx_camera;
+
+#define ORBX_GRID_COLS 64 /* FRAME_GRID_COLS, include/PresetParameters.h:8 */
+#define ORBX_GRID_ROWS 48 /* FRAME_GRID_ROWS, include/PresetParameters.h:7 */
+
+/* Frame::ComputeImageBounds (src/Frame.cc:474-501): undistorted image corners -> min/max; host code. */
+int orbx_image_bounds(const orbx_camera* cam, int width, int height, float* min_x, float* min_y,
+                      float* max_x, float* max_y);
+
+/* Frame::UndistortKeyPoints (src/Frame.cc:442-472: cv::undistortPoints(pts, pts, mK, mDistCoef,
+ * Mat(), mK), five fixed-point iterations in double; a plain copy when k1 == 0) followed by
+ * Frame::AssignFeaturesToGrid (:268-283) with PosInGrid (:420-430), for `nframes` keypoint sets of
+ * d_counts[f] (<= cap) keypoints each. d_keypoints_un receives mvKeysUn. The grid comes back in
+ * compressed form: keypoints of cell (ix, iy) are d_cell_items[f*cap + k] for
+ * k in [d_cell_start[f*3073 + ix*48 + iy], d_cell_start[f*3073 + ix*48 + iy + 1]), ascending, exactly
+ * the contents of mGrid[ix][iy]. Device pointers; enqueued on `stream` (NULL = the matcher's own). */
+int orbx_undistort_assign_grid_device(orbx_matcher* m, int nframes, int cap, const orbx_keypoint* d_keypoints,
+                                      const int32_t* d_counts, const orbx_camera* cam, float min_x, float min_y,
+                                      float max_x, float max_y, orbx_keypoint* d_keypoints_un,
+                                      int32_t* d_cell_start, int32_t* d_cell_items, void* stream);
+
 /* ---- synthetic frames (host) --------------------------------------------------------------- */
 #define ORBX_SYNTH_SCENE 0
 #define ORBX_SYNTH_ZERO 1

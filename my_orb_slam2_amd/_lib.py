@@ -27,6 +27,11 @@ class Config(C.Structure):
                 ("blur_taps", C.c_int32)]
 
 
+class Camera(C.Structure):
+    """orbx_camera: Camera.fx fy cx cy k1 k2 p1 p2 k3 of the reference's settings file."""
+    _fields_ = [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3")]
+
+
 def lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "liborbx.so")
 
@@ -74,6 +79,9 @@ SIGNATURES = {
     "orbx_compute_stereo_matches_device": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P,
                                                      C.c_float, C.c_float, _P, _P, _P]),
     "orbx_matcher_synchronize": (C.c_int, [_P]),
+    "orbx_image_bounds": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "orbx_undistort_assign_grid_device": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_float, C.c_float,
+                                                    C.c_float, C.c_float, _P, _P, _P, _P]),
     "orbx_synth_frame": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _P, C.c_size_t]),
 }

@@ -756,3 +756,43 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* lef
                                  m->scale + ORBX_MAX_LEVELS, bf, maxD, d_uright, d_depth, sad, s));
     return ORBX_OK;
 }
+
+extern "C" int orbx_image_bounds(const orbx_camera* cam, int width, int height, float* min_x, float* min_y,
+                                 float* max_x, float* max_y) {
+    if (!cam || !min_x || !min_y || !max_x || !max_y || width < 1 || height < 1) return ORBX_ERR_INVALID;
+    if (cam->k1 != 0.0f) {
+        float x[4], y[4];
+        const float cu[4] = {0.f, (float)width, 0.f, (float)width}, cv[4] = {0.f, 0.f, (float)height, (float)height};
+        for (int i = 0; i < 4; i++) undistort_point_host(*cam, cu[i], cv[i], &x[i], &y[i]);
+        *min_x = std::min(x[0], x[2]);
+        *max_x = std::max(x[1], x[3]);
+        *min_y = std::min(y[0], y[1]);
+        *max_y = std::max(y[2], y[3]);
+    } else {
+        *min_x = 0.0f;
+        *max_x = (float)width;
+        *min_y = 0.0f;
+        *max_y = (float)height;
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_undistort_assign_grid_device(orbx_matcher* m, int nframes, int cap, const orbx_keypoint* d_kps,
+                                                 const int32_t* d_counts, const orbx_camera* cam, float min_x,
+                                                 float min_y, float max_x, float max_y, orbx_keypoint* d_kps_un,
+                                                 int32_t* d_cell_start, int32_t* d_cell_items, void* stream) {
+    if (!m || nframes < 0 || cap < 1 || cap >= 0xFFFF || !cam || !(max_x > min_x) || !(max_y > min_y) ||
+        (nframes > 0 && (!d_kps || !d_counts || !d_kps_un || !d_cell_start || !d_cell_items))) {
+        set_error("orbx_undistort_assign_grid_device: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (nframes == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+    // fFrameGridElementWidthInv / HeightInv (src/Frame.cc:133-134)
+    const float invW = static_cast<float>(ORBX_GRID_COLS) / (max_x - min_x);
+    const float invH = static_cast<float>(ORBX_GRID_ROWS) / (max_y - min_y);
+    HIP_TRY(launch_undistort_grid(nframes, cap, d_kps, d_counts, *cam, min_x, min_y, invW, invH, d_kps_un,
+                                  d_cell_start, d_cell_items, s));
+    return ORBX_OK;
+}

@@ -151,4 +151,9 @@ hipError_t launch_stereo_refine(int npairs, int cap, const PyramidView& left, co
                                 const float* invScale, float bf, float maxD, float* uRight, float* depth,
                                 int32_t* sadDist, hipStream_t s);
 
+hipError_t launch_undistort_grid(int nframes, int cap, const orbx_keypoint* kps, const int32_t* counts,
+                                 orbx_camera cam, float minX, float minY, float invW, float invH,
+                                 orbx_keypoint* kpsUn, int32_t* cellStart, int32_t* cellItems, hipStream_t s);
+void undistort_point_host(const orbx_camera& cam, float u, float v, float* xo, float* yo);
+
 }  // namespace orbx

@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import check, lib, np_ptr
+from ._lib import Camera, check, lib, np_ptr
 
 # include/PresetParameters.h:11-13
 TH_HIGH = 100
@@ -107,6 +107,25 @@ class HammingMatcher:
             C.c_void_p(d_nl.data_ptr()), C.c_void_p(d_kr.data_ptr()), C.c_void_p(d_dr.data_ptr()),
             C.c_void_p(d_nr.data_ptr()), float(bf), float(b), C.c_void_p(d_uright.data_ptr()),
             C.c_void_p(d_depth.data_ptr()), sp), "orbx_compute_stereo_matches_device")
+
+    @staticmethod
+    def image_bounds(cam, width, height):
+        """Frame::ComputeImageBounds (src/Frame.cc:474-501) -> (minX, minY, maxX, maxY)."""
+        out = [C.c_float(0) for _ in range(4)]
+        check(lib().orbx_image_bounds(C.byref(cam), width, height, *[C.byref(o) for o in out]), "orbx_image_bounds")
+        return tuple(o.value for o in out)
+
+    def undistort_assign_grid_device(self, d_kps, d_counts, cam, bounds, d_kps_un, d_cell_start, d_cell_items,
+                                     stream=None):
+        """Frame::UndistortKeyPoints + AssignFeaturesToGrid for (nframes, cap, 7) keypoint tensors.
+        d_cell_start is (nframes, 64*48+1) int32, d_cell_items (nframes, cap) int32."""
+        nframes, cap = d_kps.shape[0], d_kps.shape[1]
+        sp = C.c_void_p(stream) if stream else None
+        check(lib().orbx_undistort_assign_grid_device(
+            self._m, nframes, cap, C.c_void_p(d_kps.data_ptr()), C.c_void_p(d_counts.data_ptr()), C.byref(cam),
+            float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), C.c_void_p(d_kps_un.data_ptr()),
+            C.c_void_p(d_cell_start.data_ptr()), C.c_void_p(d_cell_items.data_ptr()), sp),
+            "orbx_undistort_assign_grid_device")
 
     def synchronize(self):
         check(lib().orbx_matcher_synchronize(self._m), "orbx_matcher_synchronize")

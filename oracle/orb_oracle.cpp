@@ -904,3 +904,53 @@ extern "C" int orc_compute_stereo_matches(const orc_extractor* left, const orc_e
     }
     return kept;
 }
+
+/* cv::undistortPoints (imgproc undistort.cpp, cvUndistortPointsInternal) with R = I, P = K and
+ * TermCriteria(MAX_ITER, 5, 0.01) as called at src/Frame.cc:460,486 */
+extern "C" void orc_undistort_points(float* xy, int n, const float* K4, const float* D5) {
+    double k[14] = {0};
+    for (int i = 0; i < 5; i++) k[i] = D5[i];
+    const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double RR[3][3] = {{fx, 0, cx}, {0, fy, cy}, {0, 0, 1}};
+    for (int i = 0; i < n; i++) {
+        double x = xy[2 * i], y = xy[2 * i + 1];
+        x = (x - cx) * ifx;
+        y = (y - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+        const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+        const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+        xy[2 * i] = (float)(xx * ww);
+        xy[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+/* Frame::AssignFeaturesToGrid (src/Frame.cc:268-283) with PosInGrid (:420-430) */
+extern "C" void orc_assign_grid(const orc_keypoint* kps, int n, float minX, float minY, float maxX, float maxY,
+                                int32_t* cell_start, int32_t* cell_items) {
+    const int COLS = 64, ROWS = 48; /* include/PresetParameters.h:7-8 */
+    const float invW = static_cast<float>(COLS) / (maxX - minX);   /* src/Frame.cc:133-134 */
+    const float invH = static_cast<float>(ROWS) / (maxY - minY);
+    std::vector<std::vector<int>> grid(COLS * ROWS);
+    for (int i = 0; i < n; i++) {
+        const int posX = (int)std::round((kps[i].x - minX) * invW);
+        const int posY = (int)std::round((kps[i].y - minY) * invH);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        grid[posX * ROWS + posY].push_back(i);
+    }
+    int o = 0;
+    for (int c = 0; c < COLS * ROWS; c++) {
+        cell_start[c] = o;
+        for (int i : grid[c]) cell_items[o++] = i;
+    }
+    cell_start[COLS * ROWS] = o;
+}

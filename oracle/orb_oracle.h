@@ -109,6 +109,15 @@ int   orc_compute_stereo_matches(const orc_extractor* left, const orc_extractor*
                                  const orc_keypoint* kr, const uint8_t* dr, int nr,
                                  float bf, float b, float* uright, float* depth);
 
+/* cv::undistortPoints(pts, pts, K, D, Mat(), K) of OpenCV 4.0.0 as called by Frame::UndistortKeyPoints
+ * (src/Frame.cc:442-472) and Frame::ComputeImageBounds (:474-501): K = fx, fy, cx, cy,
+ * D = k1, k2, p1, p2, k3; five iterations in double. In place on n (x, y) float pairs. */
+void  orc_undistort_points(float* xy, int n, const float* K4, const float* D5);
+/* Frame::AssignFeaturesToGrid + PosInGrid (src/Frame.cc:268-283, 420-430): cell_start receives
+ * 64*48+1 offsets (cell = ix*48 + iy), cell_items the keypoint indices cell by cell in push_back order. */
+void  orc_assign_grid(const orc_keypoint* kps, int n, float minX, float minY, float maxX, float maxY,
+                      int32_t* cell_start, int32_t* cell_items);
+
 #ifdef __cplusplus
 }
 #endif

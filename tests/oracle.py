@@ -71,6 +71,10 @@ def lib():
                                             C.c_float, C.c_float, _P, _P]
         L.orc_compute_stereo_matches.restype = C.c_int
         L.orc_compute_stereo_matches.argtypes = [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P]
+        L.orc_undistort_points.restype = None
+        L.orc_undistort_points.argtypes = [_P, C.c_int, _P, _P]
+        L.orc_assign_grid.restype = None
+        L.orc_assign_grid.argtypes = [_P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]
         _LIB = L
     return _LIB
 
@@ -221,3 +225,19 @@ def compute_stereo_matches(ex_left, ex_right, kl, dl, kr, dr, bf, b):
                                             bf, b, ptr(ur), ptr(z))
     assert kept >= 0
     return ur, z, kept
+
+
+def undistort_points(xy, K4, D5):
+    xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2).copy()
+    K4 = np.ascontiguousarray(K4, dtype=np.float32)
+    D5 = np.ascontiguousarray(D5, dtype=np.float32)
+    lib().orc_undistort_points(ptr(xy), len(xy), ptr(K4), ptr(D5))
+    return xy
+
+
+def assign_grid(kps, bounds):
+    kps = np.ascontiguousarray(kps, dtype=KP)
+    start = np.empty(64 * 48 + 1, dtype=np.int32)
+    items = np.full(max(len(kps), 1), -1, dtype=np.int32)
+    lib().orc_assign_grid(ptr(kps), len(kps), bounds[0], bounds[1], bounds[2], bounds[3], ptr(start), ptr(items))
+    return start, items[:start[-1]]

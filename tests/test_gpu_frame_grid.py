@@ -1,0 +1,68 @@
+"""GPU parity: Frame::UndistortKeyPoints + AssignFeaturesToGrid against the oracle (bit-exact floats:
+both sides evaluate cv::undistortPoints' double-precision iteration without fused multiply-adds)."""
+import numpy as np
+import pytest
+
+import my_orb_slam2_amd as m
+from tests import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+# EuRoC mono (example_data/EuRoC_mono.yaml): Camera.fx fy cx cy k1 k2 p1 p2, k3 = 0
+EUROC = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375, k1=-0.28340811, k2=0.07395907, p1=0.00019359,
+             p2=1.76187114e-05, k3=0.0)
+
+
+def run(cam_kw, frames_idx):
+    import torch
+    cam = m.Camera(**cam_kw)
+    K4 = [cam_kw["fx"], cam_kw["fy"], cam_kw["cx"], cam_kw["cy"]]
+    D5 = [cam_kw["k1"], cam_kw["k2"], cam_kw["p1"], cam_kw["p2"], cam_kw["k3"]]
+    n = len(frames_idx)
+    ex = m.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=n)
+    cap = ex.capacity
+    frames = np.stack([m.synth_frame(i) for i in frames_idx])
+    frames[-1] = 0                                    # a frame without keypoints
+    d_kps = torch.zeros((n, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((n, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(torch.from_numpy(frames).cuda(), d_kps, d_desc, d_cnt)
+    ex.synchronize()
+    hm = m.HammingMatcher()
+    bounds = hm.image_bounds(cam, 752, 480)
+    if cam_kw["k1"] != 0:
+        c = orc.undistort_points([[0, 0], [752, 0], [0, 480], [752, 480]], K4, D5)
+        want = (min(c[0, 0], c[2, 0]), min(c[0, 1], c[1, 1]), max(c[1, 0], c[3, 0]), max(c[2, 1], c[3, 1]))
+        assert bounds == tuple(float(v) for v in want)
+    else:
+        assert bounds == (0.0, 0.0, 752.0, 480.0)
+    d_un = torch.zeros_like(d_kps)
+    d_start = torch.zeros((n, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    d_items = torch.full((n, cap), -1, dtype=torch.int32, device="cuda")
+    hm.undistort_assign_grid_device(d_kps, d_cnt, cam, bounds, d_un, d_start, d_items)
+    hm.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    view = lambda t: t.cpu().numpy().view(np.uint8).reshape(n, cap, 28).copy().view(m.KEYPOINT_DTYPE).reshape(n, cap)
+    kps, un = view(d_kps), view(d_un)
+    start, items = d_start.cpu().numpy(), d_items.cpu().numpy()
+    for f in range(n):
+        k = kps[f, :cnt[f]]
+        want = k.copy()
+        if cam_kw["k1"] != 0 and len(k):
+            xy = orc.undistort_points(np.stack([k["x"], k["y"]], 1), K4, D5)
+            want["x"], want["y"] = xy[:, 0], xy[:, 1]
+        assert np.array_equal(un[f, :cnt[f]], want), "mvKeysUn differs in frame %d" % f
+        ostart, oitems = orc.assign_grid(want, bounds)
+        assert np.array_equal(start[f], ostart)
+        assert np.array_equal(items[f, :ostart[-1]], oitems)
+    assert cnt[-1] == 0 and start[-1, -1] == 0
+    return cnt
+
+
+def test_undistort_and_grid_euroc_mono():
+    cnt = run(EUROC, [70, 71, 72, 73])
+    assert cnt[0] > 900
+
+
+def test_grid_without_distortion():
+    run(dict(EUROC, k1=0.0, k2=0.0, p1=0.0, p2=0.0), [74, 75])

@@ -307,3 +307,28 @@ def test_oracle_reproduces_golden_vectors():
     g = np.load(os.path.join(gdir, "knn2_256x4096.npz"))
     idx, d1, d2 = orc.knn2(g["query"], g["db"])
     assert np.array_equal(idx, g["idx"]) and np.array_equal(d1, g["d1"]) and np.array_equal(d2, g["d2"])
+
+
+# ---------------------------------------------------------------- undistort + grid
+def test_undistort_known_answers():
+    # no distortion coefficients: undistortPoints is the identity up to float rounding of (u-cx)/fx*fx+cx
+    K4 = [458.654, 457.296, 367.215, 248.375]
+    pts = np.array([[367.215, 248.375], [0, 0], [751, 479]], np.float32)
+    out = orc.undistort_points(pts, K4, [0, 0, 0, 0, 0])
+    assert np.abs(out - pts).max() < 1e-4
+    # the principal point is a fixed point of the distortion model
+    out = orc.undistort_points(pts[:1], K4, [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0])
+    assert np.abs(out - pts[:1]).max() < 1e-4
+    # barrel distortion (k1 < 0): undistorted corners move outwards
+    out = orc.undistort_points(pts[1:], K4, [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0])
+    assert out[0, 0] < 0 and out[0, 1] < 0 and out[1, 0] > 751 and out[1, 1] > 479
+
+
+def test_assign_grid_known_answers():
+    kps = np.zeros(5, orc.KP)
+    kps["x"] = [0, 751.9, 376, 376, -30]
+    kps["y"] = [0, 479.9, 240, 240, 10]
+    start, items = orc.assign_grid(kps, (0.0, 0.0, 752.0, 480.0))
+    # round(x * 64/752): 0 -> 0; 751.9 -> 64 (outside, dropped); 376 -> 32; -30 -> -3 (dropped)
+    assert start[-1] == 3 and list(items) == [0, 2, 3]
+    assert start[32 * 48 + 24 + 1] - start[32 * 48 + 24] == 2
