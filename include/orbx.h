@@ -220,6 +220,22 @@ int orbx_undistort_assign_grid_device(orbx_matcher* m, int nframes, int cap, con
                                       float max_x, float max_y, orbx_keypoint* d_keypoints_un,
                                       int32_t* d_cell_start, int32_t* d_cell_items, void* stream);
 
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:413-530) between two frames, host arrays in and
+ * out. For every level-0 keypoint of frame 1 the candidates are Frame::GetFeaturesInArea
+ * (src/Frame.cc:365-418) of frame 2 around prev_matched[i1] with radius window_size, levels 0..0; all
+ * candidate lists and their 256-bit distances are produced on the GPU in the reference's visiting order
+ * (grid columns, then rows, then cell contents), then the order-dependent part runs on the host exactly as
+ * written there: best / second-best with the vMatchedDistance skip (:452-453), TH_LOW and ratio tests,
+ * replacement of an earlier match of the same frame-2 keypoint, rotation histogram with
+ * ComputeThreeMaxima (:1652-1693) and the final update of prev_matched (:524-527).
+ * cell_start2 / cell_items2 are frame 2's grid as orbx_undistort_assign_grid_device returns it (host
+ * copies). matches12 receives n1 indices into frame 2 (-1 = none); *nmatches the return value. */
+int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* keys1_un, const uint8_t* desc1, int n1,
+                                   const orbx_keypoint* keys2_un, const uint8_t* desc2, int n2,
+                                   const int32_t* cell_start2, const int32_t* cell_items2, float min_x,
+                                   float min_y, float max_x, float max_y, float* prev_matched, int window_size,
+                                   float nnratio, int check_orientation, int32_t* matches12, int* nmatches);
+
 /* ---- synthetic frames (host) --------------------------------------------------------------- */
 #define ORBX_SYNTH_SCENE 0
 #define ORBX_SYNTH_ZERO 1

@@ -796,3 +796,60 @@ extern "C" int orbx_undistort_assign_grid_device(orbx_matcher* m, int nframes, i
                                   d_cell_start, d_cell_items, s));
     return ORBX_OK;
 }
+
+extern "C" int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* keys1_un, const uint8_t* desc1,
+                                              int n1, const orbx_keypoint* keys2_un, const uint8_t* desc2, int n2,
+                                              const int32_t* cell_start2, const int32_t* cell_items2, float min_x,
+                                              float min_y, float max_x, float max_y, float* prev_matched,
+                                              int window_size, float nnratio, int check_orientation,
+                                              int32_t* matches12, int* nmatches) {
+    if (!m || n1 < 0 || n2 < 0 || !nmatches || !(max_x > min_x) || !(max_y > min_y) ||
+        (n1 > 0 && (!keys1_un || !desc1 || !prev_matched || !matches12)) ||
+        (n2 > 0 && (!keys2_un || !desc2 || !cell_start2 || !cell_items2))) {
+        set_error("orbx_search_for_initialization: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const int kCells = ORBX_GRID_COLS * ORBX_GRID_ROWS;
+    const int nItems = cell_start2[kCells];
+    int maxCand = 0;                              // a query can meet every level-0 keypoint of frame 2 at most
+    for (int i = 0; i < n2; i++) maxCand += keys2_un[i].octave == 0;
+    maxCand = std::max(maxCand, 1);
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t oK1 = 0, oD1 = oK1 + up(sizeof(orbx_keypoint) * n1), oK2 = oD1 + up(32 * (size_t)n1),
+                 oD2 = oK2 + up(sizeof(orbx_keypoint) * n2), oCs = oD2 + up(32 * (size_t)n2),
+                 oCi = oCs + up(4 * (size_t)(kCells + 1)), oPv = oCi + up(4 * (size_t)std::max(nItems, 1)),
+                 oCc = oPv + up(8 * (size_t)n1), oIx = oCc + up(4 * (size_t)n1),
+                 oDs = oIx + up(4 * (size_t)n1 * maxCand), total = oDs + up(4 * (size_t)n1 * maxCand);
+    int rc = matcher_scratch(m, total, s);
+    if (rc) return rc;
+    uint8_t* base = static_cast<uint8_t*>(m->scratch);
+    HIP_TRY(hipMemcpyAsync(base + oK1, keys1_un, sizeof(orbx_keypoint) * n1, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + oD1, desc1, 32 * (size_t)n1, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + oK2, keys2_un, sizeof(orbx_keypoint) * n2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + oD2, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + oCs, cell_start2, 4 * (size_t)(kCells + 1), hipMemcpyHostToDevice, s));
+    if (nItems > 0) HIP_TRY(hipMemcpyAsync(base + oCi, cell_items2, 4 * (size_t)nItems, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + oPv, prev_matched, 8 * (size_t)n1, hipMemcpyHostToDevice, s));
+    const float invW = static_cast<float>(ORBX_GRID_COLS) / (max_x - min_x);
+    const float invH = static_cast<float>(ORBX_GRID_ROWS) / (max_y - min_y);
+    HIP_TRY(launch_window_candidates(n1, reinterpret_cast<const orbx_keypoint*>(base + oK1), base + oD1,
+                                     reinterpret_cast<const orbx_keypoint*>(base + oK2), base + oD2,
+                                     reinterpret_cast<const int32_t*>(base + oCs),
+                                     reinterpret_cast<const int32_t*>(base + oCi),
+                                     reinterpret_cast<const float*>(base + oPv), min_x, min_y, invW, invH,
+                                     (float)window_size, maxCand, reinterpret_cast<int32_t*>(base + oCc),
+                                     reinterpret_cast<int32_t*>(base + oIx), reinterpret_cast<int32_t*>(base + oDs), s));
+    std::vector<int32_t> cc(n1), ci((size_t)n1 * maxCand), cd((size_t)n1 * maxCand);
+    HIP_TRY(hipMemcpyAsync(cc.data(), base + oCc, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ci.data(), base + oIx, 4 * (size_t)n1 * maxCand, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(cd.data(), base + oDs, 4 * (size_t)n1 * maxCand, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *nmatches = replay_search_for_initialization(keys1_un, n1, keys2_un, n2, cc.data(), ci.data(), cd.data(), maxCand,
+                                                 prev_matched, nnratio, check_orientation != 0, matches12);
+    return ORBX_OK;
+}

@@ -154,6 +154,14 @@ hipError_t launch_stereo_refine(int npairs, int cap, const PyramidView& left, co
 hipError_t launch_undistort_grid(int nframes, int cap, const orbx_keypoint* kps, const int32_t* counts,
                                  orbx_camera cam, float minX, float minY, float invW, float invH,
                                  orbx_keypoint* kpsUn, int32_t* cellStart, int32_t* cellItems, hipStream_t s);
+hipError_t launch_window_candidates(int n1, const orbx_keypoint* k1, const uint8_t* d1, const orbx_keypoint* k2,
+                                    const uint8_t* d2, const int32_t* cellStart, const int32_t* cellItems,
+                                    const float* prev, float minX, float minY, float invW, float invH, float r,
+                                    int maxCand, int32_t* candCount, int32_t* candIdx, int32_t* candDist,
+                                    hipStream_t s);
+int replay_search_for_initialization(const orbx_keypoint* k1, int n1, const orbx_keypoint* k2, int n2,
+                                     const int32_t* candCount, const int32_t* candIdx, const int32_t* candDist,
+                                     int maxCand, float* prev, float nnratio, bool checkOri, int32_t* matches12);
 void undistort_point_host(const orbx_camera& cam, float u, float v, float* xo, float* yo);
 
 }  // namespace orbx

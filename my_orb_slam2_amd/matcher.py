@@ -108,6 +108,28 @@ class HammingMatcher:
             C.c_void_p(d_nr.data_ptr()), float(bf), float(b), C.c_void_p(d_uright.data_ptr()),
             C.c_void_p(d_depth.data_ptr()), sp), "orbx_compute_stereo_matches_device")
 
+    def search_for_initialization(self, keys1_un, desc1, keys2_un, desc2, cell_start2, cell_items2, bounds,
+                                  prev_matched, window_size=100, nnratio=0.9, check_orientation=True):
+        """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:413-530); the reference calls it with
+        ORBmatcher(0.9, true) and windowSize 100 (src/Tracking.cc:670). Host numpy arrays.
+        Returns (nmatches, matches12); prev_matched (n1, 2) float32 is updated in place."""
+        from ._lib import KEYPOINT_DTYPE
+        k1 = np.ascontiguousarray(keys1_un, dtype=KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(keys2_un, dtype=KEYPOINT_DTYPE)
+        d1 = np.ascontiguousarray(desc1, dtype=np.uint8)
+        d2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+        cs = np.ascontiguousarray(cell_start2, dtype=np.int32)
+        ci = np.ascontiguousarray(cell_items2, dtype=np.int32)
+        assert prev_matched.dtype == np.float32 and prev_matched.flags.c_contiguous and prev_matched.shape == (len(k1), 2)
+        out = np.empty(len(k1), dtype=np.int32)
+        n = C.c_int(0)
+        check(lib().orbx_search_for_initialization(
+            self._m, np_ptr(k1), np_ptr(d1), len(k1), np_ptr(k2), np_ptr(d2), len(k2), np_ptr(cs), np_ptr(ci),
+            float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), np_ptr(prev_matched),
+            int(window_size), float(nnratio), 1 if check_orientation else 0, np_ptr(out), C.byref(n)),
+            "orbx_search_for_initialization")
+        return n.value, out
+
     @staticmethod
     def image_bounds(cam, width, height):
         """Frame::ComputeImageBounds (src/Frame.cc:474-501) -> (minX, minY, maxX, maxY)."""

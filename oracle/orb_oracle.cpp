@@ -954,3 +954,111 @@ extern "C" void orc_assign_grid(const orc_keypoint* kps, int n, float minX, floa
     }
     cell_start[COLS * ROWS] = o;
 }
+
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:413-530) */
+extern "C" int orc_search_for_initialization(const orc_keypoint* k1, const uint8_t* d1, int n1,
+                                             const orc_keypoint* k2, const uint8_t* d2, int n2, float minX,
+                                             float minY, float maxX, float maxY, float* prev, int windowSize,
+                                             float mfNNratio, int checkOri, int32_t* vnMatches12) {
+    const int COLS = 64, ROWS = 48, HISTO_LENGTH = 30, TH_LOW = 50;
+    const float invW = static_cast<float>(COLS) / (maxX - minX), invH = static_cast<float>(ROWS) / (maxY - minY);
+    /* mGrid of frame 2 (src/Frame.cc:268-283) */
+    std::vector<std::vector<uint32_t>> grid(COLS * ROWS);
+    for (int i = 0; i < n2; i++) {
+        const int posX = (int)std::round((k2[i].x - minX) * invW), posY = (int)std::round((k2[i].y - minY) * invH);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        grid[posX * ROWS + posY].push_back((uint32_t)i);
+    }
+    /* Frame::GetFeaturesInArea (src/Frame.cc:365-418) */
+    auto features_in_area = [&](float x, float y, float r, int minLevel, int maxLevel) {
+        std::vector<size_t> v;
+        const int nMinCellX = std::max(0, (int)std::floor((x - minX - r) * invW));
+        if (nMinCellX >= COLS) return v;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - minX + r) * invW));
+        if (nMaxCellX < 0) return v;
+        const int nMinCellY = std::max(0, (int)std::floor((y - minY - r) * invH));
+        if (nMinCellY >= ROWS) return v;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - minY + r) * invH));
+        if (nMaxCellY < 0) return v;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (uint32_t j : grid[ix * ROWS + iy]) {
+                    const orc_keypoint& kp = k2[j];
+                    if (bCheckLevels) {
+                        if (kp.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                    }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) v.push_back(j);
+                }
+        return v;
+    };
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1);
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = k1[i1].octave;
+        if (level1 > 0) continue;
+        std::vector<size_t> vIndices2 = features_in_area(prev[2 * i1], prev[2 * i1 + 1], (float)windowSize, level1, level1);
+        if (vIndices2.empty()) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            const int dist = orc_hamming256(d1 + 32 * (size_t)i1, d2 + 32 * i2);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestIdx2 = (int)i2;
+            } else if (dist < bestDist2) {
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_LOW) {
+            if (bestDist < (float)bestDist2 * mfNNratio) {
+                if (vnMatches21[bestIdx2] >= 0) {
+                    vnMatches12[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOri) {
+                    float rot = k1[i1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)std::round(rot / (360 * factor));
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(i1);
+                }
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) { /* ComputeThreeMaxima (:1652-1693) */
+            const int s = (int)rotHist[i].size();
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i])
+                if (vnMatches12[idx1] >= 0) {
+                    vnMatches12[idx1] = -1;
+                    nmatches--;
+                }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (vnMatches12[i1] >= 0) {
+            prev[2 * i1] = k2[vnMatches12[i1]].x;
+            prev[2 * i1 + 1] = k2[vnMatches12[i1]].y;
+        }
+    return nmatches;
+}

@@ -118,6 +118,14 @@ void  orc_undistort_points(float* xy, int n, const float* K4, const float* D5);
 void  orc_assign_grid(const orc_keypoint* kps, int n, float minX, float minY, float maxX, float maxY,
                       int32_t* cell_start, int32_t* cell_items);
 
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:413-530) with Frame::GetFeaturesInArea
+ * (src/Frame.cc:365-418) and ComputeThreeMaxima (src/ORBmatcher.cc:1652-1693). Frame 2's grid is built
+ * internally with orc_assign_grid. prev_matched (n1 x 2) is updated in place. Returns nmatches. */
+int   orc_search_for_initialization(const orc_keypoint* k1, const uint8_t* d1, int n1,
+                                    const orc_keypoint* k2, const uint8_t* d2, int n2,
+                                    float minX, float minY, float maxX, float maxY, float* prev_matched,
+                                    int window_size, float nnratio, int check_orientation, int32_t* matches12);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,9 @@ def lib():
         L.orc_undistort_points.argtypes = [_P, C.c_int, _P, _P]
         L.orc_assign_grid.restype = None
         L.orc_assign_grid.argtypes = [_P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]
+        L.orc_search_for_initialization.restype = C.c_int
+        L.orc_search_for_initialization.argtypes = [_P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float, C.c_float,
+                                                    C.c_float, _P, C.c_int, C.c_float, C.c_int, _P]
         _LIB = L
     return _LIB
 
@@ -241,3 +244,16 @@ def assign_grid(kps, bounds):
     items = np.full(max(len(kps), 1), -1, dtype=np.int32)
     lib().orc_assign_grid(ptr(kps), len(kps), bounds[0], bounds[1], bounds[2], bounds[3], ptr(start), ptr(items))
     return start, items[:start[-1]]
+
+
+def search_for_initialization(k1, d1, k2, d2, bounds, prev, window=100, nnratio=0.9, check_ori=True):
+    k1 = np.ascontiguousarray(k1, dtype=KP)
+    k2 = np.ascontiguousarray(k2, dtype=KP)
+    d1 = np.ascontiguousarray(d1, dtype=np.uint8)
+    d2 = np.ascontiguousarray(d2, dtype=np.uint8)
+    prev = np.ascontiguousarray(prev, dtype=np.float32).copy()
+    out = np.empty(len(k1), dtype=np.int32)
+    n = lib().orc_search_for_initialization(ptr(k1), ptr(d1), len(k1), ptr(k2), ptr(d2), len(k2), bounds[0], bounds[1],
+                                            bounds[2], bounds[3], ptr(prev), window, nnratio, 1 if check_ori else 0,
+                                            ptr(out))
+    return n, out, prev

@@ -66,3 +66,26 @@ def test_undistort_and_grid_euroc_mono():
 
 def test_grid_without_distortion():
     run(dict(EUROC, k1=0.0, k2=0.0, p1=0.0, p2=0.0), [74, 75])
+
+
+def test_search_for_initialization():
+    """Mono initialisation matching between two views of the same scene (second view: objects shifted by
+    their disparity), through undistort + grid + SearchForInitialization, against the oracle."""
+    cam = dict(EUROC, k1=0.0, k2=0.0, p1=0.0, p2=0.0)
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    ex = m.ORBextractor(2000, 1.2, 8, 20, 7)           # the initialisation extractor uses 2 * nFeatures
+    hm = m.HammingMatcher()
+    for idx, check_ori in ((80, True), (81, False)):
+        k1, d1 = ex(m.synth_frame(idx))
+        k2, d2 = ex(m.synth_frame(idx, right_view=True))
+        start, items = orc.assign_grid(k2, bounds)
+        prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32).copy()   # mvbPrevMatched = keypoint positions
+        want_n, want, want_prev = orc.search_for_initialization(k1, d1, k2, d2, bounds, prev, 100, 0.9, check_ori)
+        n, got = hm.search_for_initialization(k1, d1, k2, d2, start, items, bounds, prev, 100, 0.9, check_ori)
+        assert n == want_n and np.array_equal(got, want)
+        assert np.array_equal(prev, want_prev)
+        assert n > 20 and (got >= 0).sum() == n
+    # empty second frame
+    n, got = hm.search_for_initialization(k1, d1, k2[:0], d2[:0], np.zeros(64 * 48 + 1, np.int32), np.zeros(1, np.int32),
+                                          bounds, prev)
+    assert n == 0 and np.all(got == -1)
