@@ -8,6 +8,9 @@
 #pragma once
 
 #include <cstdint>
+#include <cstring>
+#include <istream>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -127,5 +130,32 @@ private:
 
 // ORBmatcher::DescriptorDistance on two 32-byte descriptor rows (src/ORBmatcher.cc:1698-1714).
 inline int DescriptorDistance(const uint8_t* a, const uint8_t* b) { return orbx_hamming256(a, b); }
+
+// Keypoint / descriptor block of the reference's binary map file (src/KeyFrame.cc:934-942 written through
+// DUtils/IoUtils.cpp:4-33): a uint64 count followed by raw 28-byte cv::KeyPoint records, and a matrix as
+// {rows, cols, type} uint32 header (type 0 = CV_8UC1) followed by rows*cols bytes. orbx_keypoint has the
+// cv::KeyPoint layout, so maps written by either side load on the other.
+inline void WriteKeyPoints(std::ostream& f, const std::vector<orbx_keypoint>& kps) {
+    const uint64_t size = kps.size();
+    f.write(reinterpret_cast<const char*>(&size), sizeof(size));
+    f.write(reinterpret_cast<const char*>(kps.data()), static_cast<std::streamsize>(size * sizeof(orbx_keypoint)));
+}
+inline void ReadKeyPoints(std::istream& f, std::vector<orbx_keypoint>& kps) {
+    uint64_t size = 0;
+    f.read(reinterpret_cast<char*>(&size), sizeof(size));
+    kps.resize(size);
+    f.read(reinterpret_cast<char*>(kps.data()), static_cast<std::streamsize>(size * sizeof(orbx_keypoint)));
+}
+inline void WriteDescriptors(std::ostream& f, const std::vector<uint8_t>& desc) {
+    const uint32_t header[3] = {static_cast<uint32_t>(desc.size() / ORBX_DESC_BYTES), ORBX_DESC_BYTES, 0u};
+    f.write(reinterpret_cast<const char*>(header), sizeof(header));
+    f.write(reinterpret_cast<const char*>(desc.data()), static_cast<std::streamsize>(desc.size()));
+}
+inline void ReadDescriptors(std::istream& f, std::vector<uint8_t>& desc) {
+    uint32_t header[3] = {0, 0, 0};
+    f.read(reinterpret_cast<char*>(header), sizeof(header));
+    desc.resize(static_cast<size_t>(header[0]) * header[1]);
+    f.read(reinterpret_cast<char*>(desc.data()), static_cast<std::streamsize>(desc.size()));
+}
 
 }  // namespace ORB_SLAM2

@@ -1,6 +1,7 @@
 // Exercises the C++ shim the way Frame::ExtractORB does and prints a digest that the Python test
 // compares with the oracle's result for the same synthetic frame.
 #include <cstdio>
+#include <sstream>
 #include <vector>
 
 #include "ORBextractorGpu.h"
@@ -19,6 +20,16 @@ int main() {
                 k.size(), ex.GetLevels(), ex.GetScaleFactors()[1], h, k[0].x, k[0].y, k[0].angle,
                 ex.mvImagePyramid[1].cols, ex.mvImagePyramid[1].rows, (int)ex.mvImagePyramid[1].ptr()[0],
                 ORB_SLAM2::DescriptorDistance(d.data(), d.data() + 32));
+    // map-file block: count + raw 28-byte records, {rows, cols, type} + bytes; round trip
+    std::stringstream ss;
+    ORB_SLAM2::WriteKeyPoints(ss, k);
+    ORB_SLAM2::WriteDescriptors(ss, d);
+    if (ss.str().size() != 8 + 28 * k.size() + 12 + d.size()) return 4;
+    std::vector<orbx_keypoint> kb;
+    std::vector<uint8_t> db;
+    ORB_SLAM2::ReadKeyPoints(ss, kb);
+    ORB_SLAM2::ReadDescriptors(ss, db);
+    if (kb.size() != k.size() || std::memcmp(kb.data(), k.data(), 28 * k.size()) != 0 || db != d) return 5;
     // empty image: outputs untouched
     std::vector<orbx_keypoint> k2(3);
     std::vector<uint8_t> d2(5);
