@@ -25,24 +25,29 @@ namespace orbx {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kLdsPoints = 6144;  // candidates of one level held in LDS; more spill to global memory
+constexpr int kLdsPoints = 2048;  // candidates of one level held in LDS; more spill to global memory.
+                                  // Small on purpose: the kernel is latency-bound, so more resident
+                                  // workgroups per CU matter more than keeping rare big levels in LDS.
 
 // Inclusive scan of data[0..n) in place. `part` holds kThreads ints. All threads must call.
+// Each thread owns a run of ceil(n / 256) elements; run totals are scanned inside each wave with
+// lane shuffles and the four wave totals are combined through LDS: two barriers in all.
 __device__ void block_scan_inclusive(int* data, int n, int* part) {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int per = (n + kThreads - 1) / kThreads;
-    const int b = t * per, e = min(b + per, n);
+    const int b = min(t * per, n), e = min(b + per, n);
     int s = 0;
     for (int i = b; i < e; i++) s += data[i];
-    part[t] = s;
-    __syncthreads();
-    for (int off = 1; off < kThreads; off <<= 1) {
-        const int v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    int incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
     }
-    int run = t ? part[t - 1] : 0;
+    if (lane == 63) part[wv] = incl;
+    __syncthreads();
+    int run = incl - s;
+    for (int w = 0; w < wv; w++) run += part[w];
     for (int i = b; i < e; i++) {
         run += data[i];
         data[i] = run;
@@ -277,17 +282,20 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
     const int cb = min(t * per, nCells), ce = min(cb + per, nCells);
     int mine = 0;
     for (int c = cb; c < ce; c++) mine += counts[c];
-    __syncthreads();
-    part[t] = mine;
-    __syncthreads();
-    for (int off = 1; off < kThreads; off <<= 1) {
-        const int v = t >= off ? part[t - off] : 0;
+    int incl = mine;
+    {
+        const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) part[wv] = incl;
         __syncthreads();
-        part[t] += v;
-        __syncthreads();
+        for (int w = 0; w < wv; w++) incl += part[w];
     }
-    const int P = part[kThreads - 1];
-    int dst = part[t] - mine;
+    const int P = part[0] + part[1] + part[2] + part[3];
+    int dst = incl - mine;
     __syncthreads();
     if (P == 0) {
         if (t == 0) *selCountOut = 0;
@@ -306,7 +314,16 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
     for (int c = cb; c < ce; c++) {
         const int n = counts[c];
         const uint32_t* src = slots + (long long)c * L.slotCap;
-        for (int k = 0; k < n; k++) cand[dst++] = src[k];
+        // eight loads in flight per batch instead of one dependent load per entry
+        for (int k0 = 0; k0 < n; k0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = k0 + k < n ? src[k0 + k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k0 + k < n) cand[dst + k] = v[k];
+            dst += min(8, n - k0);
+        }
     }
     __syncthreads();
     if (inLds)
