@@ -28,36 +28,47 @@ __device__ __forceinline__ int div_small(int i, int recip) { return (int)(((unsi
 template <int pitch>
 __device__ __forceinline__ int corner_strength(const uint8_t* p) {
     const int v = p[0];
-    int d[16];
-    d[0] = v - p[3 * pitch];
-    d[1] = v - p[3 * pitch + 1];
-    d[2] = v - p[2 * pitch + 2];
-    d[3] = v - p[pitch + 3];
-    d[4] = v - p[3];
-    d[5] = v - p[-pitch + 3];
-    d[6] = v - p[-2 * pitch + 2];
-    d[7] = v - p[-3 * pitch + 1];
-    d[8] = v - p[-3 * pitch];
-    d[9] = v - p[-3 * pitch - 1];
-    d[10] = v - p[-2 * pitch - 2];
-    d[11] = v - p[-pitch - 3];
-    d[12] = v - p[-3];
-    d[13] = v - p[pitch - 3];
-    d[14] = v - p[2 * pitch - 2];
-    d[15] = v - p[3 * pitch - 1];
+    // With d_k = v - c_k: max over arcs of min(d) = v - min over arcs of max(c), and
+    // min over arcs of max(d) = v - max over arcs of min(c); so the sixteen differences are never formed.
+    int c[16];
+    c[0] = p[3 * pitch];
+    c[1] = p[3 * pitch + 1];
+    c[2] = p[2 * pitch + 2];
+    c[3] = p[pitch + 3];
+    c[4] = p[3];
+    c[5] = p[-pitch + 3];
+    c[6] = p[-2 * pitch + 2];
+    c[7] = p[-3 * pitch + 1];
+    c[8] = p[-3 * pitch];
+    c[9] = p[-3 * pitch - 1];
+    c[10] = p[-2 * pitch - 2];
+    c[11] = p[-pitch - 3];
+    c[12] = p[-3];
+    c[13] = p[pitch - 3];
+    c[14] = p[2 * pitch - 2];
+    c[15] = p[3 * pitch - 1];
     int lo3[16], hi3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-        hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        lo3[k] = min(min(c[k], c[(k + 1) & 15]), c[(k + 2) & 15]);
+        hi3[k] = max(max(c[k], c[(k + 1) & 15]), c[(k + 2) & 15]);
     }
-    int a = -256, b = 256;
+    int hiMin = 256, loMax = -1;   // smallest arc maximum, largest arc minimum
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        a = max(a, min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]));  // darker arc of 9 from k
-        b = min(b, max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]));  // brighter arc of 9 from k
+    for (int k = 0; k < 16; k += 2) {
+        const int h0 = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
+        const int h1 = max(max(hi3[k + 1], hi3[(k + 4) & 15]), hi3[(k + 7) & 15]);
+        hiMin = min(min(hiMin, h0), h1);
+        const int l0 = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
+        const int l1 = min(min(lo3[k + 1], lo3[(k + 4) & 15]), lo3[(k + 7) & 15]);
+        loMax = max(max(loMax, l0), l1);
     }
-    return max(a, -b);
+    return max(v - hiMin, loMax - v);      // darker-arc strength, brighter-arc strength
+}
+
+// number of set bits of m below this lane's own
+__device__ __forceinline__ int prefix_count(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
 }  // namespace
@@ -172,19 +183,19 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     wave_sync();
 
     // ---- 2. cheap test at the low threshold, queue survivors in row-major order ----
-    const int npix = sw * sh;
-    const int recipSw = (65536 + sw - 1) / sw;
+    // Lanes map to whole rows: two rows of 32 lanes when the scan is at most 32 px wide, else one row of
+    // 64, so stepping to the next rows is one add on the LDS address. A queue entry is (y << 8) | x.
     const int tlow = min(iniTh, minTh);
+    const bool narrow = sw <= 32;
+    const int rowLanes = narrow ? 32 : 64, rowsPerIter = narrow ? 2 : 1;
+    const int lx = lane & (rowLanes - 1), ly = narrow ? lane >> 5 : 0;
     int nq = 0;
-    // lane's pixel (x, y) advances by 64 positions per iteration without any multiply
-    const int dy64 = 64 / sw, dx64 = 64 - dy64 * sw;
-    int py = div_small(lane, recipSw), px = lane - py * sw;
-    int addr = (py + 3) * pitch + xo + px + 3;
-    for (int base = 0; base < npix; base += 64) {
-        const int i = base + lane;
-        bool pass = false;
-        if (i < npix) {
-            const uint8_t* p = tile + addr;
+    {
+        const bool inRow = lx < sw;                    // cells are < 60 px wide (width / floor(width / 30))
+        int yx = (ly << 8) | lx;
+        const int yxEnd = sh << 8;
+        const uint8_t* p = tile + (ly + 3) * pitch + xo + lx + 3;
+        for (int y0 = 0; y0 < sh; y0 += rowsPerIter) {
             const int v = p[0];
             // circle pixel k and its antipode k+8: a run of 9 holds at least one of each pair
             const int p0 = p[3 * pitch], p8 = p[-3 * pitch];
@@ -193,17 +204,14 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
             // eight pairs reject ~85% of the pixels; what passes goes straight to the exact strength.
             const int mnmax = max(min(p0, p8), min(p4, p12));
             const int mxmin = min(max(p0, p8), max(p4, p12));
-            pass = mnmax < v - tlow || mxmin > v + tlow;
+            // (bitwise, not short-circuit: the whole test stays branch-free lane-mask arithmetic)
+            const bool pass = ((mnmax < v - tlow) | (mxmin > v + tlow)) & inRow & (yx < yxEnd);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+            if (pass) queue[nq + prefix_count(m)] = (uint16_t)yx;
+            nq += __popcll(m);
+            yx += rowsPerIter << 8;
+            p += rowsPerIter * pitch;
         }
-        px += dx64;
-        addr += dy64 * pitch + dx64;
-        if (px >= sw) {
-            px -= sw;
-            addr += pitch - sw;
-        }
-        const unsigned long long m = __ballot(pass);
-        if (pass) queue[nq + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
-        nq += __popcll(m);
     }
     wave_sync();
 
@@ -211,17 +219,16 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     int nc = 0;
     for (int base = 0; base < nq; base += 64) {
         const int qi = base + lane;
-        int i = 0, S = 0;
+        int yx = 0, S = 0;
         if (qi < nq) {
-            i = queue[qi];
-            const int y = div_small(i, recipSw);
-            const int x = i - y * sw;
+            yx = queue[qi];
+            const int y = yx >> 8, x = yx & 255;
             S = corner_strength<PITCH>(tile + (y + 3) * pitch + xo + x + 3);
             if (S > tlow) score[(y + 1) * sp + x + 1] = (uint8_t)S; else S = 0;
         }
-        const unsigned long long m = __ballot(S > 0);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(S > 0);
         // in-place compaction: position nc+prefix <= qi, and every lane has read queue[qi] above
-        if (S > 0) queue[nc + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+        if (S > 0) queue[nc + prefix_count(m)] = (uint16_t)yx;
         nc += __popcll(m);
     }
     wave_sync();
@@ -235,9 +242,9 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
             bool keep = false;
             int x = 0, y = 0, sc = 0;
             if (qi < nc) {
-                const int i = queue[qi];
-                y = div_small(i, recipSw);
-                x = i - y * sw;
+                const int yx = queue[qi];
+                y = yx >> 8;
+                x = yx & 255;
                 const uint8_t* s = score + (y + 1) * sp + x + 1;
                 const int S = s[0];
                 if (S > t) {
@@ -249,9 +256,9 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
                     keep = sc > nbScore;
                 }
             }
-            const unsigned long long m = __ballot(keep);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
             if (keep) {
-                const int pos = nout + __popcll(m & ((1ull << lane) - 1));
+                const int pos = nout + prefix_count(m);
                 // FAST reports sub-image coordinates (x+3, y+3); the caller adds j*wCell, i*hCell (:814-815)
                 if (pos < L.slotCap) slotOut[pos] = pack_cand(cj * L.wCell + x + 3, ci * L.hCell + y + 3, sc);
             }

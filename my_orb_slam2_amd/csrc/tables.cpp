@@ -132,6 +132,10 @@ bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g,
     // A staged cell row holds up to 3 bytes of alignment slack + the cell + 6 px, rounded up to
     // dwords; every level of a launch uses the same pitch: 48 bytes when all cells fit, else 80.
     g.tilePitch = ((3 + maxWCell + 6 + 3) & ~3) <= 48 ? 48 : 80;
+    if (maxWCell > 64 || maxHCell > 64) {   // cannot happen: a cell is width / floor(width / 30) < 60 px
+        err = "FAST cell larger than 64 px";
+        return false;
+    }
     g.maxTileBytes = g.tilePitch * (maxHCell + 6);
     g.totalCells = cells;
     g.totalSlots = slots;
