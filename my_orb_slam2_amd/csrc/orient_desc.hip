@@ -8,11 +8,17 @@
 // rotated pattern, +3 for the 7x7 taps), blurs it there with the same separable 8.8 fixed-point
 // filter (u16 row sums, 16.16 column sums, one rounding at the end: cv fixedSmoothInvoker), and
 // samples the blurred patch. No blurred level is ever written to HBM.
-//   R  raw bytes, 43 rows x 48 B, columns aligned to a dword of the image row (coalesced dword loads)
+//   R  raw bytes, 44 rows x 48 B; LDS column j is image column kx - 23 + j for every keypoint (the
+//      dword loads are re-aligned with v_alignbyte on the way in), so all later indices are constants
 //   T  row sums as u16 (they never exceed 257*255), rows 2j and 2j+1 packed into one dword per column,
-//      22 x 44 dwords: four outputs per lane from three raw dwords via v_alignbyte + v_dot4_u32_u8
-//   Bl blurred bytes, 37 x 44 (overlays R once the row pass is done): four outputs per lane, each from
-//      four v_dot2_u32_u16 over the packed row pairs (the 7 taps straddle 4 pairs either way round)
+//      22 x 44 dwords. One lane makes both rows of a pair for four columns (v_alignbyte +
+//      v_dot4_u32_u8) and stores them as one 16-byte write.
+//   Bl blurred bytes, 38 x 44 (overlays R once the row pass is done). One lane makes blurred rows 2p
+//      and 2p+1 for four columns from the same four packed row pairs (v_dot2_u32_u16; the 7 taps
+//      straddle the pairs as (K0,K1)(K2,K3)(K4,K5)(K6,-) for the even row and (-,K0)(K1,K2)(K3,K4)(K5,K6)
+//      for the odd one).
+// Only what the rotated pattern can reach is blurred: its points lie within radius sqrt(338) of the
+// keypoint, so the work items of both passes come from tables built at compile time for that disc.
 // orbx_debug_blur_level() runs the same arithmetic over a full level for parity tests.
 #include "orbx_internal.h"
 
@@ -20,22 +26,36 @@ namespace orbx {
 
 namespace {
 
-__device__ const int8_t c_pattern[1024] = {
+// rBRIEF pattern as floats: x0, y0, x1, y1 per pair
+__device__ const float c_patternf[1024] = {
 #include "../../include/orbx_pattern31.inc"
 };
 
 // End of each row of the radius-15 disc (umax, src/ORBextractor.cc:446-461).
 constexpr int kUmax[kHalfPatch + 1] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
-// Byte weights for the intensity-centroid sums, four columns per dword: row |v| (16) x dword q (8),
-// column u = 4q - 15 + byte. Set 0: 1 inside the disc (plain row sum); set 1: u + 15 inside the disc.
+constexpr int kPR = 21;                 // patch radius
+constexpr int kRowsAlloc = 44;          // 43 patch rows, staged in fours; Bl row 37 also lands in the spare row
+constexpr int kRPitch = 48;             // bytes per raw row (12 dwords)
+constexpr int kCx = 23;                 // LDS column of the keypoint
+constexpr int kTPitch = 44;             // dwords per packed row pair of T, bytes per row of Bl
+constexpr int kTPairs = 22;             // row pairs of T (43 rows)
+constexpr int kBlRows = 37;             // blurred rows: patch rows 3..39
+constexpr int kWavesPerBlock = 4;
+constexpr int kWaveLds = kRowsAlloc * kRPitch + kTPairs * kTPitch * 4;  // 2112 + 3872 bytes
+constexpr int kHIters = 3, kVIters = 3; // 64-item rounds of the row pass and of the column pass
+
+// Byte weights for the intensity-centroid sums, four columns per dword: patch row v + 15 (32, the last
+// one all zero) x dword q (8), column u = 4q - 15 + byte. .x: 1 inside the disc (plain row sum);
+// .y: u + 15 inside the disc.
 struct MomentWeights {
-    uint32_t w[2][16][8];
+    uint32_t w[32][8][2];
 };
 constexpr MomentWeights make_moment_weights() {
     MomentWeights m{};
-    for (int av = 0; av < 16; av++)
+    for (int row = 0; row < 31; row++)
         for (int q = 0; q < 8; q++) {
+            const int av = row < 15 ? 15 - row : row - 15;
             uint32_t w0 = 0, w1 = 0;
             for (int b = 0; b < 4; b++) {
                 const int u = 4 * q - 15 + b;
@@ -45,23 +65,70 @@ constexpr MomentWeights make_moment_weights() {
                     w1 |= (uint32_t)(u + 15) << (8 * b);
                 }
             }
-            m.w[0][av][q] = w0;
-            m.w[1][av][q] = w1;
+            m.w[row][q][0] = w0;
+            m.w[row][q][1] = w1;
         }
     return m;
 }
 __device__ const MomentWeights c_momw = make_moment_weights();
 
-constexpr int kPR = 21;                 // patch radius
-constexpr int kRows = 2 * kPR + 1;      // 43 patch rows
-constexpr int kRPitch = 48;             // bytes per raw row (12 dwords)
-constexpr int kTPitch = 44;             // dwords per packed row pair of T, bytes per row of Bl
-constexpr int kTPairs = 22;             // row pairs of T (43 rows)
-constexpr int kGroups = 10;             // 4-column groups blurred per row (40 columns cover cx-18..cx+18)
-constexpr int kBlRows = 37;             // blurred rows: patch rows 3..39
-constexpr int kWavesPerBlock = 4;
-constexpr int kWaveLds = kRows * kRPitch + kTPairs * kTPitch * 4;  // 2064 + 3872 bytes
-constexpr int kMomLds = 2 * 16 * 8 * 4;                             // moment weights, shared by the block
+// Can the rounded, rotated pattern land on offset (dx, dy)? Its real position is within radius sqrt(338)
+// (the farthest pattern point is (-13,-13)); (dx, dy) is reachable if its unit box touches that disc.
+constexpr bool reachable(int dx, int dy) {
+    const int nx = dx < 0 ? -2 * dx - 1 : 2 * dx - 1, ny = dy < 0 ? -2 * dy - 1 : 2 * dy - 1;  // twice the box's nearest point
+    const int px = nx < 0 ? 0 : nx, py = ny < 0 ? 0 : ny;
+    return px * px + py * py <= 4 * 338 + 2;
+}
+// blurred row y (0..36, dy = y - 18), column group gg (columns 4gg .. 4gg+3, dx = column - 23)
+constexpr bool blur_group_needed(int y, int gg) {
+    if (y < 0 || y >= kBlRows) return false;
+    for (int b = 0; b < 4; b++)
+        if (reachable(4 * gg + b - kCx, y - 18)) return true;
+    return false;
+}
+// patch row r (0..42) feeds blurred rows r-6 .. r
+constexpr bool rowsum_group_needed(int r, int gg) {
+    for (int y = r - 6; y <= r; y++)
+        if (blur_group_needed(y, gg)) return true;
+    return false;
+}
+// Work items. Row pass: patch row pair j, group gg -> (byte offset in R of the dword left of the group in
+// row 2j) | (byte offset in T of the pair's four dwords) << 16. Column pass: blurred row pair p, group gg ->
+// (byte offset in T of pair p's dwords) | (byte offset in Bl of row 2p's dword) << 16. Spare slots repeat
+// item 0 (same inputs, same stores).
+struct ItemTables {
+    uint32_t h[kHIters * 64];
+    uint32_t v[kVIters * 64];
+    int nh, nv;
+};
+constexpr ItemTables make_item_tables() {
+    ItemTables t{};
+    int nh = 0, nv = 0;
+    for (int j = 0; j < kTPairs; j++)
+        for (int gg = 1; gg <= 10; gg++)
+            if (rowsum_group_needed(2 * j, gg) || rowsum_group_needed(2 * j + 1, gg)) {
+                if (nh < kHIters * 64)
+                    t.h[nh] = (uint32_t)(2 * j * kRPitch + (gg - 1) * 4) | (uint32_t)((j * kTPitch + 4 * gg) * 4) << 16;
+                nh++;
+            }
+    for (int p = 0; 2 * p < kBlRows; p++)
+        for (int gg = 1; gg <= 10; gg++)
+            if (blur_group_needed(2 * p, gg) || blur_group_needed(2 * p + 1, gg)) {
+                if (nv < kVIters * 64)
+                    t.v[nv] = (uint32_t)((p * kTPitch + 4 * gg) * 4) | (uint32_t)(2 * p * kTPitch + 4 * gg) << 16;
+                nv++;
+            }
+    t.nh = nh;
+    t.nv = nv;
+    for (int i = nh; i < kHIters * 64; i++) t.h[i] = t.h[0];
+    for (int i = nv; i < kVIters * 64; i++) t.v[i] = t.v[0];
+    return t;
+}
+constexpr ItemTables kItems = make_item_tables();
+static_assert(kItems.nh <= kHIters * 64 && kItems.nv <= kVIters * 64, "work item tables overflow");
+__device__ const ItemTables c_items = make_item_tables();
+
+constexpr int kMomLds = 32 * 8 * 2 * 4;   // moment weights, shared by the block
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     p = p < 0 ? -p : p;
@@ -89,6 +156,54 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+// sin and cos of x in [0, 8] to within an ulp of double (the reference takes cos/sin of the angle in double and
+// rounds to float, src/ORBextractor.cc:103-104). Quadrant reduction with a two-part pi/2, then the
+// minimax polynomials of fdlibm's __kernel_sin / __kernel_cos on |r| <= pi/4.
+__device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
+    const double kq = __builtin_rint(x * 6.36619772367581382433e-01);             // x * 2/pi, 0..5
+    double r = __builtin_fma(-kq, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-kq, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = __builtin_fma(z * r, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double cs = w + (((1.0 - w) - hz) + z * z * pc);
+    const int n = (int)kq;
+    const double so = (n & 1) ? cs : sn, co = (n & 1) ? sn : cs;
+    *s = (n & 2) ? -so : so;
+    *c = ((n + 1) & 2) ? -co : co;
+}
+
+// Sum over the wave; every lane must be active. The total is returned to all lanes.
+__device__ __forceinline__ int wave_sum(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);  // row_mirror: every lane holds its row's sum
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+// Orders a wave's own LDS traffic (one wave's DS instructions execute in order).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t row_sum4(uint32_t x, uint32_t klo, uint32_t khi, uint32_t y) {
+    return __builtin_amdgcn_udot4(x, klo, __builtin_amdgcn_udot4(y, khi, 0u, false), false);
+}
+
 }  // namespace
 
 template <bool ALIGNED4>
@@ -102,211 +217,182 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the set-up scalar
     const int f = blockIdx.x;                     // frame-fastest grid: one frame per XCD
     const int slot = blockIdx.y * kWavesPerBlock + wv;    // index into the frame's selected regions
-    uint32_t* momw = reinterpret_cast<uint32_t*>(s_mem + kWavesPerBlock * kWaveLds);
-    momw[threadIdx.x] = (&c_momw.w[0][0][0])[threadIdx.x];
-    // No wave leaves before the last barrier; inactive waves just skip the work.
-    bool active = slot < g.totalSel;
-    int l = 0, k = 0, outIdx = 0, kx = 0, ky = 0, cx = kPR;
-    uint32_t packed = 0;
-    if (active) {
-        while (l + 1 < g.nlevels && slot >= g.lv[l + 1].selBase) l++;
-        k = slot - g.lv[l].selBase;
-        const int32_t* selCount = fs.selCount + (long long)f * g.nlevels;
-        // position in the frame's output: levels are concatenated in order (:1067-1096)
-        int before = 0, total = 0;
-        for (int i = 0; i < g.nlevels; i++) {
-            const int c = selCount[i];
-            before += i < l ? c : 0;
-            total += c;
-        }
-        if (slot == 0 && lane == 0) countsOut[f] = total;
-        outIdx = before + k;
-        active = k < selCount[l] && outIdx < cap;
+    uint2* momw = reinterpret_cast<uint2*>(s_mem + kWavesPerBlock * kWaveLds);
+    momw[threadIdx.x] = reinterpret_cast<const uint2*>(&c_momw.w[0][0][0])[threadIdx.x];
+    __syncthreads();                              // the only block-wide step; waves are independent after it
+    if (slot >= g.totalSel) return;
+    int l = 0;
+    while (l + 1 < g.nlevels && slot >= g.lv[l + 1].selBase) l++;
+    const int k = slot - g.lv[l].selBase;
+    const int32_t* selCount = fs.selCount + (long long)f * g.nlevels;
+    // position in the frame's output: levels are concatenated in order (:1067-1096)
+    int before = 0, total = 0;
+    for (int i = 0; i < g.nlevels; i++) {
+        const int c = selCount[i];
+        before += i < l ? c : 0;
+        total += c;
     }
+    if (slot == 0 && lane == 0) countsOut[f] = total;
+    const int outIdx = before + k;
+    if (k >= selCount[l] || outIdx >= cap) return;
     const LevelGeom& L = g.lv[l];
-    uint8_t* R = s_mem + wv * kWaveLds;                                   // raw patch, later Bl
-    uint32_t* T = reinterpret_cast<uint32_t*>(R + kRows * kRPitch);      // packed row sums
-    if (active) {
-        packed = fs.sel[(long long)f * g.totalSel + slot];
-        kx = cand_x(packed) + kBorder;   // level coordinates (:835-836)
-        ky = cand_y(packed) + kBorder;
-        const uint8_t* img;
-        long long rowStride;
-        if (l == 0) {
-            img = fs.img + (long long)f * fs.imgFrameStride;
-            rowStride = fs.imgRowStride;
+    uint8_t* R = s_mem + wv * kWaveLds;                                        // raw patch, later Bl
+    uint8_t* Tb = R + kRowsAlloc * kRPitch;                                    // packed row sums
+    uint32_t* R32 = reinterpret_cast<uint32_t*>(R);
+
+    // work items of both blur passes (independent of everything else: their latency hides behind the staging)
+    uint32_t hItem[kHIters], vItem[kVIters];
+#pragma unroll
+    for (int q = 0; q < kHIters; q++) hItem[q] = c_items.h[64 * q + lane];
+#pragma unroll
+    for (int q = 0; q < kVIters; q++) vItem[q] = c_items.v[64 * q + lane];
+
+    const uint32_t packed = fs.sel[(long long)f * g.totalSel + slot];
+    const int kx = cand_x(packed) + kBorder;   // level coordinates (:835-836)
+    const int ky = cand_y(packed) + kBorder;
+    const uint8_t* img;
+    int rowStride;
+    if (l == 0) {
+        img = fs.img + (long long)f * fs.imgFrameStride;
+        rowStride = (int)fs.imgRowStride;
+    } else {
+        img = fs.pyr + (long long)f * g.pyrBytes + L.offset;
+        rowStride = L.stride;
+    }
+    // ---- stage the raw patch: LDS column j <-> image column kx-23+j, LDS row r <-> image row ky-21+r ----
+    // Columns kx-21 .. kx+21 are used. When they all lie inside the level the rows come in as dwords: lane
+    // (row slot, dword d) reads the two aligned dwords around its four bytes; dwords that stick out of the
+    // row are clamped into it (they only hold unused columns). Rows outside the level are reflected.
+    if (kx - kPR >= 0 && kx + kPR < L.w && (ALIGNED4 || l > 0)) {
+        const int xa = (kx - kCx) & ~3;
+        const uint32_t shift = (uint32_t)((kx - kCx) & 3);
+        const int d = lane & 15, rs = lane >> 4;
+        const int colLo = min(max(xa + 4 * d, 0), rowStride - 4), colHi = min(max(xa + 4 * d + 4, 0), rowStride - 4);
+        const bool rowsInside = ky - kPR >= 0 && ky - kPR + kRowsAlloc <= L.h;
+        uint32_t lo[kRowsAlloc / 4], hi[kRowsAlloc / 4];
+        if (rowsInside) {
+            const uint8_t* src = img + (long long)(ky - kPR + rs) * rowStride;
+#pragma unroll
+            for (int q = 0; q < kRowsAlloc / 4; q++) {
+                lo[q] = *reinterpret_cast<const uint32_t*>(src + colLo);
+                hi[q] = *reinterpret_cast<const uint32_t*>(src + colHi);
+                src += 4 * (long long)rowStride;
+            }
         } else {
-            img = fs.pyr + (long long)f * g.pyrBytes + L.offset;
-            rowStride = L.stride;
+#pragma unroll
+            for (int q = 0; q < kRowsAlloc / 4; q++) {
+                const int sy = reflect101(ky - kPR + rs + 4 * q, L.h);
+                const uint8_t* src = img + (long long)sy * rowStride;
+                lo[q] = *reinterpret_cast<const uint32_t*>(src + colLo);
+                hi[q] = *reinterpret_cast<const uint32_t*>(src + colHi);
+            }
         }
-        // ---- stage the raw patch: LDS column j <-> image column xa + j, LDS row r <-> image row ky-21+r ----
-        const int xa = (kx - kPR) & ~3;
-        const bool interior = kx - kPR >= 0 && kx + kPR < L.w && ky - kPR >= 0 && ky + kPR < L.h &&
-                              xa + kRPitch <= rowStride && (ALIGNED4 || l > 0);
-        if (interior) {
-            cx = kx - xa;
-            uint32_t* R32 = reinterpret_cast<uint32_t*>(R);
-            // lane + 64q -> (row, dword): 64 = 5*12 + 4, so both advance without a division; all loads
-            // are issued before the first LDS store so their latencies overlap
-            constexpr int kIter = (kRows * 12 + 63) / 64;
-            int r = lane / 12, d = lane - r * 12;
-            const uint8_t* src = img + (long long)(ky - kPR + r) * rowStride + xa + d * 4;
-            uint32_t v[kIter];
+        if (d < 12) {
 #pragma unroll
-            for (int q = 0; q < kIter; q++) {
-                v[q] = r < kRows ? *reinterpret_cast<const uint32_t*>(src) : 0u;
-                d += 4;
-                r += 5;
-                src += 5 * rowStride + 16;
-                if (d >= 12) {
-                    d -= 12;
-                    r += 1;
-                    src += rowStride - 48;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < kIter; q++)
-                if (lane + 64 * q < kRows * 12) R32[lane + 64 * q] = v[q];
-        } else {
-            // near the level border or unaligned caller memory: bytes, BORDER_REFLECT_101 coordinates
-            cx = kPR;
-            for (int i = lane; i < kRows * kRPitch; i += 64) {
-                const int r = i / kRPitch, c = i - r * kRPitch;
-                const int sy = reflect101(ky - kPR + r, L.h), sx = reflect101(kx - kPR + c, L.w);
-                R[i] = img[(long long)sy * rowStride + sx];
-            }
+            for (int q = 0; q < kRowsAlloc / 4; q++)
+                R32[(rs + 4 * q) * 12 + d] = __builtin_amdgcn_alignbyte(hi[q], lo[q], shift);
+        }
+    } else {
+        // within two pixels of the level's left/right border, or unaligned caller memory: bytes,
+        // BORDER_REFLECT_101 coordinates
+        for (int i = lane; i < kRowsAlloc * kRPitch; i += 64) {
+            const int r = i / kRPitch, c = i - r * kRPitch;
+            const int sy = reflect101(ky - kPR + r, L.h), sx = reflect101(kx - kCx + c, L.w);
+            R[i] = img[(long long)sy * rowStride + sx];
         }
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- intensity centroid on the unblurred patch (:69-96) ----
-    float angle = 0.f;
-    const int g0 = (cx - 18) >> 2;     // first blurred 4-column group: columns 4*g0 .. 4*g0+39 cover cx-18 .. cx+18
-    if (active) {
-        // m01 = sum v*I, m10 = sum u*I over the disc; each lane takes dwords (four columns) of the 31x31
-        // window: row sums with 0/1 byte weights, sum (u+15)*I with byte weights, both by v_dot4_u32_u8
-        const uint32_t* R32 = reinterpret_cast<const uint32_t*>(R);
-        const int c0 = cx - kHalfPatch;            // first column of the window
-        const uint32_t sh = (uint32_t)(c0 & 3);
-        int s0 = 0, s1 = 0, m01 = 0;
+    // m01 = sum v*I, m10 = sum u*I over the disc; each lane takes dwords (four columns) of the 31x31
+    // window (columns 8..39 of R): row sums with 0/1 byte weights, sum (u+15)*I with byte weights
+    int s0 = 0, s1 = 0, m01 = 0;
+    {
+        const uint32_t* Rw = R32 + (kPR - kHalfPatch) * 12 + (kCx - kHalfPatch) / 4 + (lane >> 3) * 12 + (lane & 7);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int i = lane + 64 * q;           // 31 rows x 8 dwords = 248 items
-            if (i < 31 * 8) {
-                const int row = i >> 3, dq = i & 7;
-                const int v = row - kHalfPatch, av = abs(v);
-                const int di = (kPR + v) * 12 + (c0 >> 2) + dq;
-                const uint32_t D = __builtin_amdgcn_alignbyte(R32[di + 1], R32[di], sh);
-                const uint32_t rs = __builtin_amdgcn_udot4(D, momw[av * 8 + dq], 0u, false);
-                s0 += (int)rs;
-                m01 += v * (int)rs;
-                s1 = (int)__builtin_amdgcn_udot4(D, momw[128 + av * 8 + dq], (uint32_t)s1, false);
-            }
-        }
-        int m10 = s1 - kHalfPatch * s0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            m10 += __shfl_xor(m10, off);
-            m01 += __shfl_xor(m01, off);
-        }
-        angle = fast_atan2_deg((float)m01, (float)m10);
-
-        // ---- row pass: T[r][j] = sum_c K[c] * R[r][j-3+c], four columns per lane ----
-        const uint32_t klo = blurTaps == ORBX_BLUR_CV_4_0_0 ? 0x37312212u : 0x38302212u;  // K0..K3
-        const uint32_t khi = blurTaps == ORBX_BLUR_CV_4_0_0 ? 0x00122231u : 0x00122230u;  // K4..K6
-        int r = lane / kGroups, gq = lane - r * kGroups;      // 64 = 6*10 + 4
-#pragma unroll
-        for (int q = 0; q < (kRows * kGroups + 63) / 64; q++) {
-            if (r < kRows) {
-                const int gg = g0 + gq;
-                const uint32_t A = gg ? R32[r * 12 + gg - 1] : 0u;   // columns 4g-4 .. 4g-1
-                const uint32_t B = R32[r * 12 + gg];                 // columns 4g   .. 4g+3
-                const uint32_t C = R32[r * 12 + gg + 1];             // columns 4g+4 .. 4g+7
-                uint4 o;
-                o.x = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 1), klo,
-                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 1), khi, 0u, false), false);
-                o.y = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 2), klo,
-                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 2), khi, 0u, false), false);
-                o.z = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(B, A, 3), klo,
-                      __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, B, 3), khi, 0u, false), false);
-                o.w = __builtin_amdgcn_udot4(B, klo, __builtin_amdgcn_udot4(C, khi, 0u, false), false);
-                // row r is the low (even r) or high (odd r) half of pair r/2
-                uint16_t* t16 = reinterpret_cast<uint16_t*>(T + (r >> 1) * kTPitch + 4 * gg) + (r & 1);
-                t16[0] = (uint16_t)o.x;
-                t16[2] = (uint16_t)o.y;
-                t16[4] = (uint16_t)o.z;
-                t16[6] = (uint16_t)o.w;
-            }
-            gq += 4;
-            r += 6;
-            if (gq >= kGroups) {
-                gq -= kGroups;
-                r += 1;
-            }
+            const uint32_t D = Rw[q * 8 * 12];
+            const uint2 w = momw[lane + 64 * q];
+            const uint32_t rs = __builtin_amdgcn_udot4(D, w.x, 0u, false);
+            s0 += (int)rs;
+            m01 += ((lane >> 3) + 8 * q - kHalfPatch) * (int)rs;
+            s1 = (int)__builtin_amdgcn_udot4(D, w.y, (uint32_t)s1, false);
         }
     }
-    __syncthreads();
+    const int m10 = wave_sum(s1 - kHalfPatch * s0);
+    m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- row pass: T[r][j] = sum_c K[c] * R[r][j-3+c]; a lane makes rows 2j, 2j+1 of four columns ----
+    const uint32_t klo = blurTaps == ORBX_BLUR_CV_4_0_0 ? 0x37312212u : 0x38302212u;  // K0..K3
+    const uint32_t khi = blurTaps == ORBX_BLUR_CV_4_0_0 ? 0x00122231u : 0x00122230u;  // K4..K6
+#pragma unroll
+    for (int q = 0; q < kHIters; q++) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(R + (hItem[q] & 0xFFFFu));
+        uint4 o[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t A = p[12 * h], B = p[12 * h + 1], C = p[12 * h + 2];   // columns 4g-4 .. 4g+7
+            o[h].x = row_sum4(__builtin_amdgcn_alignbyte(B, A, 1), klo, khi, __builtin_amdgcn_alignbyte(C, B, 1));
+            o[h].y = row_sum4(__builtin_amdgcn_alignbyte(B, A, 2), klo, khi, __builtin_amdgcn_alignbyte(C, B, 2));
+            o[h].z = row_sum4(__builtin_amdgcn_alignbyte(B, A, 3), klo, khi, __builtin_amdgcn_alignbyte(C, B, 3));
+            o[h].w = row_sum4(B, klo, khi, C);
+        }
+        *reinterpret_cast<uint4*>(Tb + (hItem[q] >> 16)) =
+            make_uint4(o[0].x | (o[1].x << 16), o[0].y | (o[1].y << 16), o[0].z | (o[1].z << 16), o[0].w | (o[1].w << 16));
+    }
+    wave_sync();
 
     // ---- column pass: Bl[y][j] = min(255, (sum_r K[r] * T[y+r][j] + 32768) >> 16), y = patch row - 3 ----
-    if (active) {
-        // taps as u16 pairs. Blurred row y uses patch rows y..y+6; for even y those are the pairs
-        // (y,y+1)(y+2,y+3)(y+4,y+5)(y+6,-), for odd y (-,y)(y+1,y+2)(y+3,y+4)(y+5,y+6).
+    {
         const uint32_t k2 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 49u : 48u, k3 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 55u : 56u;
         const uint32_t we[4] = {18u | (34u << 16), k2 | (k3 << 16), k2 | (34u << 16), 18u};
         const uint32_t wo[4] = {18u << 16, 34u | (k2 << 16), k3 | (k2 << 16), 34u | (18u << 16)};
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        uint32_t* Bl32 = reinterpret_cast<uint32_t*>(R);
-        int y = lane / kGroups, gq = lane - y * kGroups;
 #pragma unroll
-        for (int q = 0; q < (kBlRows * kGroups + 63) / 64; q++) {
-            if (y < kBlRows) {
-                const int gg = g0 + gq;
-                uint4 acc = make_uint4(32768u, 32768u, 32768u, 32768u);
-                const bool odd = y & 1;
-                const uint32_t* tp = T + (y >> 1) * kTPitch + 4 * gg;
+        for (int q = 0; q < kVIters; q++) {
+            const uint8_t* tp = Tb + (vItem[q] & 0xFFFFu);
+            uint4 e = make_uint4(32768u, 32768u, 32768u, 32768u), o = e;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint4 t = *reinterpret_cast<const uint4*>(tp + r * kTPitch);
-                    const us2 w = __builtin_bit_cast(us2, odd ? wo[r] : we[r]);
-                    acc.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), w, acc.x, false);
-                    acc.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), w, acc.y, false);
-                    acc.z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.z), w, acc.z, false);
-                    acc.w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.w), w, acc.w, false);
-                }
-                Bl32[y * (kTPitch / 4) + gg] = min(acc.x >> 16, 255u) | (min(acc.y >> 16, 255u) << 8) |
-                                               (min(acc.z >> 16, 255u) << 16) | (min(acc.w >> 16, 255u) << 24);
+            for (int r = 0; r < 4; r++) {
+                const uint4 t = *reinterpret_cast<const uint4*>(tp + r * kTPitch * 4);
+                const us2 a = __builtin_bit_cast(us2, we[r]), b = __builtin_bit_cast(us2, wo[r]);
+                e.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), a, e.x, false);
+                e.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), a, e.y, false);
+                e.z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.z), a, e.z, false);
+                e.w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.w), a, e.w, false);
+                o.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), b, o.x, false);
+                o.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), b, o.y, false);
+                o.z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.z), b, o.z, false);
+                o.w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.w), b, o.w, false);
             }
-            gq += 4;
-            y += 6;
-            if (gq >= kGroups) {
-                gq -= kGroups;
-                y += 1;
-            }
+            uint32_t* bl = reinterpret_cast<uint32_t*>(R + (vItem[q] >> 16));
+            bl[0] = min(e.x >> 16, 255u) | (min(e.y >> 16, 255u) << 8) | (min(e.z >> 16, 255u) << 16) |
+                    (min(e.w >> 16, 255u) << 24);
+            bl[kTPitch / 4] = min(o.x >> 16, 255u) | (min(o.y >> 16, 255u) << 8) | (min(o.z >> 16, 255u) << 16) |
+                              (min(o.w >> 16, 255u) << 24);
         }
     }
-    __syncthreads();
-    if (!active) return;
+    wave_sync();
 
     // ---- steered BRIEF on the blurred patch (:99-139) ----
-    const uint8_t* Bl = R;
     const float rad = __fmul_rn(angle, (float)(3.14159265358979323846 / 180.f));
     double sd, cd;
-    sincos((double)rad, &sd, &cd);
+    sincos_small((double)rad, &sd, &cd);
     const float a = (float)cd, b = (float)sd;
     unsigned long long* desc64 = reinterpret_cast<unsigned long long*>(descOut + ((long long)f * cap + outIdx) * 32);
-    const int base = (kPR - 3) * kTPitch + cx;   // blurred row y <-> patch row y + 3
+    const uint8_t* Bl = R + (kPR - 3) * kTPitch + kCx;   // blurred row y <-> patch row y + 3
+    const float4* pat = reinterpret_cast<const float4*>(c_patternf);
 #pragma unroll
     for (int round = 0; round < 4; round++) {
-        const int pair = round * 64 + lane;
-        const char4 pt = *reinterpret_cast<const char4*>(c_pattern + 4 * pair);
-        const float x0 = (float)pt.x, y0 = (float)pt.y, x1 = (float)pt.z, y1 = (float)pt.w;
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = Bl[base + r0 * kTPitch + c0];
-        const int t1 = Bl[base + r1 * kTPitch + c1];
-        const unsigned long long bits = __ballot(t0 < t1);
+        const float4 pt = pat[round * 64 + lane];        // x0, y0, x1, y1
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+        const int t0 = Bl[r0 * kTPitch + c0];
+        const int t1 = Bl[r1 * kTPitch + c1];
+        const unsigned long long bits = __builtin_amdgcn_ballot_w64(t0 < t1);
         if (lane == 0) desc64[round] = bits;   // pair 64*round + j is bit j%8 of byte 8*round + j/8
     }
     if (lane == 0) {
