@@ -26,10 +26,24 @@ namespace orbx {
 
 namespace {
 
-// rBRIEF pattern as floats: x0, y0, x1, y1 per pair
-__device__ const float c_patternf[1024] = {
+// rBRIEF pattern (x0, y0, x1, y1 per pair); the kernel reads it as floats reordered to x0, x1, y0, y1
+constexpr int kPatternInt[1024] = {
 #include "../../include/orbx_pattern31.inc"
 };
+struct PatternF {
+    float v[1024];
+};
+constexpr PatternF make_pattern_f() {
+    PatternF p{};
+    for (int i = 0; i < 256; i++) {
+        p.v[4 * i + 0] = (float)kPatternInt[4 * i + 0];
+        p.v[4 * i + 1] = (float)kPatternInt[4 * i + 2];
+        p.v[4 * i + 2] = (float)kPatternInt[4 * i + 1];
+        p.v[4 * i + 3] = (float)kPatternInt[4 * i + 3];
+    }
+    return p;
+}
+__device__ const PatternF c_patternf_tab = make_pattern_f();
 
 // End of each row of the radius-15 disc (umax, src/ORBextractor.cc:446-461).
 constexpr int kUmax[kHalfPatch + 1] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
@@ -246,6 +260,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     for (int q = 0; q < kHIters; q++) hItem[q] = c_items.h[64 * q + lane];
 #pragma unroll
     for (int q = 0; q < kVIters; q++) vItem[q] = c_items.v[64 * q + lane];
+    float4 patv[4];                                // this lane's four pattern pairs, fetched just as early
+#pragma unroll
+    for (int q = 0; q < 4; q++) patv[q] = reinterpret_cast<const float4*>(c_patternf_tab.v)[64 * q + lane];
 
     const uint32_t packed = fs.sel[(long long)f * g.totalSel + slot];
     const int kx = cand_x(packed) + kBorder;   // level coordinates (:835-836)
@@ -315,7 +332,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
             const uint2 w = momw[lane + 64 * q];
             const uint32_t rs = __builtin_amdgcn_udot4(D, w.x, 0u, false);
             s0 += (int)rs;
-            m01 += ((lane >> 3) + 8 * q - kHalfPatch) * (int)rs;
+            m01 += __mul24((lane >> 3) + 8 * q - kHalfPatch, (int)rs);
             s1 = (int)__builtin_amdgcn_udot4(D, w.y, (uint32_t)s1, false);
         }
     }
@@ -382,16 +399,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     const float a = (float)cd, b = (float)sd;
     unsigned long long* desc64 = reinterpret_cast<unsigned long long*>(descOut + ((long long)f * cap + outIdx) * 32);
     const uint8_t* Bl = R + (kPR - 3) * kTPitch + kCx;   // blurred row y <-> patch row y + 3
-    const float4* pat = reinterpret_cast<const float4*>(c_patternf);
+    // the table holds x0, x1, y0, y1 per pair so that both points go through packed float instructions
+    // (IEEE single products and sums, rounded separately, as the reference's scalar code)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 aa = {a, a}, bb = {b, b};
+    const f32x2 kMagic = {12582912.f, 12582912.f};                                       // 0x4B400000
+    constexpr uint32_t kMagicBias = 0x400000u * (uint32_t)kTPitch + 0x4B400000u;        // what the raw bits add
 #pragma unroll
     for (int round = 0; round < 4; round++) {
-        const float4 pt = pat[round * 64 + lane];        // x0, y0, x1, y1
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
-        const int t0 = Bl[r0 * kTPitch + c0];
-        const int t1 = Bl[r1 * kTPitch + c1];
+        const float4 pt = patv[round];
+        const f32x2 px = {pt.x, pt.y}, py = {pt.z, pt.w};
+        const f32x2 rr = px * bb + py * aa;              // x*b + y*a (:110-112)
+        const f32x2 cc = px * aa - py * bb;              // x*a - y*b
+        // cvRound (:111): adding 1.5 * 2^23 rounds to the nearest integer, ties to even, and leaves it in the
+        // low mantissa bits (|value| < 2^22); v_mad_u32_u24 then forms 44*row + column on the raw bit patterns
+        const f32x2 rm = rr + kMagic, cm = cc + kMagic;
+        const uint32_t i0 = __umul24(__float_as_uint(rm.x), (uint32_t)kTPitch) + __float_as_uint(cm.x);
+        const uint32_t i1 = __umul24(__float_as_uint(rm.y), (uint32_t)kTPitch) + __float_as_uint(cm.y);
+        const int t0 = Bl[(int)(i0 - kMagicBias)];
+        const int t1 = Bl[(int)(i1 - kMagicBias)];
         const unsigned long long bits = __builtin_amdgcn_ballot_w64(t0 < t1);
         if (lane == 0) desc64[round] = bits;   // pair 64*round + j is bit j%8 of byte 8*round + j/8
     }
