@@ -75,6 +75,7 @@ __device__ __forceinline__ int prefix_count(unsigned long long m) {
 
 // PITCH is the LDS row pitch of the staged cell (bytes, multiple of 4); a compile-time constant so that
 // all sixteen circle offsets fold into the ds_read immediate offsets.
+constexpr int kTileRowBatch = 40;    // tile rows staged per round of loads; the tile area is a multiple of it
 constexpr int kCellsPerBlock = 4;   // waves per workgroup; every wave works alone on its own cell and LDS slice
 
 // Orders a wave's own LDS traffic: the hardware runs one wave's DS instructions in order, so only the
@@ -132,35 +133,28 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
         const int xa = iniX & ~3;
         const int ndw = (maxX - xa + 3) >> 2;
         xo = iniX - xa;
-        // lane + 64q -> (row, dword) advances without a division; the first eight loads of a lane are
-        // all issued before the first LDS store so their latencies overlap (covers cells up to 12 x 42 dwords)
-        const int recip = (65536 + ndw - 1) / ndw;
-        const int dyn = 64 / ndw, dxn = 64 - dyn * ndw;
-        uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile);
-        int ty = div_small(lane, recip), td = lane - ty * ndw;
-        const uint8_t* src = img + (long long)(iniY + ty) * rowStride + xa + td * 4;
-        int li = ty * (PITCH / 4) + td;
-        while (ty < th) {                      // wave-uniform trip count is not needed: lanes just idle
-            uint32_t v[8];
-            int idx[8];
+        // A row of the tile is at most PITCH/4 dwords: 16 lanes (four rows per step) or 32 lanes (two rows)
+        // take one row each, so stepping to the next rows is one add on the source pointer and a constant on
+        // the LDS side. Ten loads are in flight before the first LDS store.
+        constexpr int kRowLanes = PITCH <= 64 ? 16 : 32, kRowsPerStep = 64 / kRowLanes;
+        constexpr int kBatch = kTileRowBatch / kRowsPerStep;
+        const int td = lane & (kRowLanes - 1), tr = lane / kRowLanes;
+        uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile) + tr * (PITCH / 4) + td;
+        // 32-bit offsets from the level's (wave-uniform) base. Rows past the tile re-read its last row, so no
+        // load leaves the level; they are stored too (the tile area holds whole batches of rows), which
+        // keeps every load and store unconditional.
+        const uint32_t col = (uint32_t)(xa + td * 4), stride32 = (uint32_t)rowStride;
+        if (td < ndw) {
+            for (int r0 = 0; r0 < th; r0 += kTileRowBatch) {
+                uint32_t v[kBatch];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                idx[q] = ty < th ? li : -1;
-                v[q] = ty < th ? *reinterpret_cast<const uint32_t*>(src) : 0u;
-                td += dxn;
-                ty += dyn;
-                src += (long long)dyn * rowStride + dxn * 4;
-                li += dyn * (PITCH / 4) + dxn;
-                if (td >= ndw) {
-                    td -= ndw;
-                    ty += 1;
-                    src += rowStride - ndw * 4;
-                    li += PITCH / 4 - ndw;
+                for (int q = 0; q < kBatch; q++) {
+                    const uint32_t row = (uint32_t)(iniY + min(r0 + tr + kRowsPerStep * q, th - 1));
+                    v[q] = *reinterpret_cast<const uint32_t*>(img + (size_t)(__umul24(row, stride32) + col));
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < 8; q++)
-                if (idx[q] >= 0) tile32[idx[q]] = v[q];
+                for (int q = 0; q < kBatch; q++) tile32[(r0 + kRowsPerStep * q) * (PITCH / 4)] = v[q];
+            }
         }
     } else {
         const int tw = maxX - iniX;

@@ -136,7 +136,7 @@ bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g,
         err = "FAST cell larger than 64 px";
         return false;
     }
-    g.maxTileBytes = g.tilePitch * (maxHCell + 6);
+    g.maxTileBytes = g.tilePitch * ((maxHCell + 6 + 39) / 40 * 40);   // fast_cells stages rows in batches of 40
     g.totalCells = cells;
     g.totalSlots = slots;
     g.totalSel = sel;
