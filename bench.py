@@ -7,7 +7,7 @@ already sits in HBM through the whole hot path (pyramid, FAST cells, quadtree, o
 outputs stay on the device.  N > 1: one process per GPU, every rank extracts its own frames, no
 data-path collective ("scaling": "weak").
 
-    python bench.py --gpus 1 --steps 16 --warmup 2
+    python bench.py --gpus 1 --steps 64 --warmup 4
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -46,8 +46,8 @@ STAGE_BYTES = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=256, help="frames per step and GPU")
     ap.add_argument("--unique", type=int, default=1024, help="distinct synthetic frames per GPU (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,6 +201,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(dom)
+    # what actually bounds the kernel (profiles/valu.json, from the PMC passes of tools/profile_gpu.sh):
+    # wave64 VALU instructions x 4 issue cycles per SIMD against the kernel's cycles
+    vpath = os.path.join(ROOT, "profiles", "valu.json")
+    valu = json.load(open(vpath)).get(dom) if os.path.exists(vpath) else None
     out = {
         "metric": "ORB frames/s (752x480, 8 lvl, 1000 kp)",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -215,6 +219,7 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": dom_bytes,
                      "kernel_ms": round(acc[dom], 4),
+                     "valu_issue": valu,
                      "stage_ms": {k: round(v, 4) for k, v in acc.items()},
                      "path_bytes_per_frame": BYTES_PER_FRAME,
                      "path_achieved": round(BYTES_PER_FRAME * fps / world / 1e9, 2),
