@@ -236,6 +236,28 @@ int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* keys1_u
                                    float min_y, float max_x, float max_y, float* prev_matched, int window_size,
                                    float nnratio, int check_orientation, int32_t* matches12, int* nmatches);
 
+/* ORBmatcher::SearchByBoW, host arrays in and out. mode ORBX_BOW_KEYFRAME_FRAME follows
+ * SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:153-293): side 1 is the keyframe
+ * (keys1_un = mvKeysUn, valid1[i] != 0 where the keyframe holds a live map point), side 2 the frame
+ * (keys2 = mvKeys; valid2 is not read); matches receives n2 entries: the keyframe feature whose map point
+ * frame feature i2 gets, or -1; acceptance bestDist1 <= TH_LOW (:231). mode ORBX_BOW_KEYFRAME_KEYFRAME
+ * follows SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (:532-690): both sides carry valid flags, matches
+ * receives n1 entries (index into side 2 or -1), acceptance bestDist1 < TH_LOW (:619).
+ * A feature vector (DBoW3::FeatureVector, a map node id -> feature indices) is passed flattened:
+ * fvK_nodes ascending node ids, features of node j are fvK_items[fvK_start[j] .. fvK_start[j+1]).
+ * The 256-bit distances of every (live left feature, right feature) pair inside a common node are made on
+ * the GPU; the greedy, order-dependent pass over them (skip of already matched features, best / second best,
+ * TH_LOW and ratio tests, rotation histogram with ComputeThreeMaxima :1652-1693) runs on the host as
+ * written in the reference. *nmatches receives the return value. */
+#define ORBX_BOW_KEYFRAME_FRAME 0
+#define ORBX_BOW_KEYFRAME_KEYFRAME 1
+int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint* keys1_un, const uint8_t* desc1,
+                       const uint8_t* valid1, int n1, const uint32_t* fv1_nodes, const int32_t* fv1_start,
+                       const uint32_t* fv1_items, int fv1_n, const orbx_keypoint* keys2, const uint8_t* desc2,
+                       const uint8_t* valid2, int n2, const uint32_t* fv2_nodes, const int32_t* fv2_start,
+                       const uint32_t* fv2_items, int fv2_n, float nnratio, int check_orientation,
+                       int32_t* matches, int* nmatches);
+
 /* ---- synthetic frames (host) --------------------------------------------------------------- */
 #define ORBX_SYNTH_SCENE 0
 #define ORBX_SYNTH_ZERO 1

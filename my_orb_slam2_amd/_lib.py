@@ -82,6 +82,8 @@ SIGNATURES = {
     "orbx_search_for_initialization": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, C.c_float, C.c_float,
                                                  C.c_float, C.c_float, _P, C.c_int, C.c_float, C.c_int, _P,
                                                  C.POINTER(C.c_int)]),
+    "orbx_search_by_bow": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int,
+                                     _P, _P, _P, C.c_int, C.c_float, C.c_int, _P, C.POINTER(C.c_int)]),
     "orbx_image_bounds": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "orbx_undistort_assign_grid_device": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_float, C.c_float,
                                                     C.c_float, C.c_float, _P, _P, _P, _P]),

@@ -797,6 +797,61 @@ extern "C" int orbx_undistort_assign_grid_device(orbx_matcher* m, int nframes, i
     return ORBX_OK;
 }
 
+extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint* keys1_un, const uint8_t* desc1,
+                                  const uint8_t* valid1, int n1, const uint32_t* fv1_nodes,
+                                  const int32_t* fv1_start, const uint32_t* fv1_items, int fv1_n,
+                                  const orbx_keypoint* keys2, const uint8_t* desc2, const uint8_t* valid2, int n2,
+                                  const uint32_t* fv2_nodes, const int32_t* fv2_start, const uint32_t* fv2_items,
+                                  int fv2_n, float nnratio, int check_orientation, int32_t* matches,
+                                  int* nmatches) {
+    const bool kfkf = mode == ORBX_BOW_KEYFRAME_KEYFRAME;
+    if (!m || (mode != ORBX_BOW_KEYFRAME_FRAME && !kfkf) || n1 < 0 || n2 < 0 || fv1_n < 0 || fv2_n < 0 || !nmatches ||
+        (n1 > 0 && (!keys1_un || !desc1 || !valid1)) || (n2 > 0 && (!keys2 || !desc2 || (kfkf && !valid2))) ||
+        (fv1_n > 0 && (!fv1_nodes || !fv1_start || !fv1_items)) ||
+        (fv2_n > 0 && (!fv2_nodes || !fv2_start || !fv2_items)) || ((kfkf ? n1 : n2) > 0 && !matches)) {
+        set_error("orbx_search_by_bow: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    for (int j = 0; j + 1 < fv1_n; j++)
+        if (!(fv1_nodes[j] < fv1_nodes[j + 1])) { set_error("orbx_search_by_bow: fv1_nodes not ascending"); return ORBX_ERR_INVALID; }
+    for (int j = 0; j + 1 < fv2_n; j++)
+        if (!(fv2_nodes[j] < fv2_nodes[j + 1])) { set_error("orbx_search_by_bow: fv2_nodes not ascending"); return ORBX_ERR_INVALID; }
+    *nmatches = 0;
+    const int nout = kfkf ? n1 : n2;
+    for (int i = 0; i < nout; i++) matches[i] = -1;
+    std::vector<BowRow> rows;
+    long long npairs = 0;
+    if (!build_bow_rows(fv1_nodes, fv1_start, fv1_items, fv1_n, valid1, n1, fv2_nodes, fv2_start, fv2_items, fv2_n, n2,
+                        rows, npairs)) {
+        set_error("orbx_search_by_bow: feature vector index out of range");
+        return ORBX_ERR_INVALID;
+    }
+    if (rows.empty() || npairs == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const int nItems2 = fv2_start[fv2_n];
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t oD1 = 0, oD2 = oD1 + up(32 * (size_t)n1), oIt = oD2 + up(32 * (size_t)n2),
+                 oRw = oIt + up(4 * (size_t)nItems2), oDs = oRw + up(sizeof(BowRow) * rows.size()),
+                 total = oDs + up(2 * (size_t)npairs);
+    int rc = matcher_scratch(m, total, s);
+    if (rc) return rc;
+    uint8_t* base = static_cast<uint8_t*>(m->scratch);
+    HIP_TRY(hipMemcpyAsync(base + oD1, desc1, 32 * (size_t)n1, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + oD2, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + oIt, fv2_items, 4 * (size_t)nItems2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(base + oRw, rows.data(), sizeof(BowRow) * rows.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_bow_distances((int)rows.size(), reinterpret_cast<const BowRow*>(base + oRw), base + oD1,
+                                 reinterpret_cast<const uint32_t*>(base + oIt), base + oD2,
+                                 reinterpret_cast<uint16_t*>(base + oDs), s));
+    std::vector<uint16_t> dist((size_t)npairs);
+    HIP_TRY(hipMemcpyAsync(dist.data(), base + oDs, 2 * (size_t)npairs, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *nmatches = replay_search_by_bow(mode, rows, dist.data(), fv2_items, keys1_un, keys2, valid2, n1, n2, nnratio,
+                                     check_orientation != 0, matches);
+    return ORBX_OK;
+}
+
 extern "C" int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* keys1_un, const uint8_t* desc1,
                                               int n1, const orbx_keypoint* keys2_un, const uint8_t* desc2, int n2,
                                               const int32_t* cell_start2, const int32_t* cell_items2, float min_x,

@@ -154,6 +154,19 @@ hipError_t launch_stereo_refine(int npairs, int cap, const PyramidView& left, co
 hipError_t launch_undistort_grid(int nframes, int cap, const orbx_keypoint* kps, const int32_t* counts,
                                  orbx_camera cam, float minX, float minY, float invW, float invH,
                                  orbx_keypoint* kpsUn, int32_t* cellStart, int32_t* cellItems, hipStream_t s);
+// One distance row of SearchByBoW: left feature idx1 against count2 right-hand features listed from
+// items2[start2]; its distances go to dist[out ..].
+struct BowRow {
+    int32_t idx1, start2, count2, out;
+};
+hipError_t launch_bow_distances(int nrows, const BowRow* rows, const uint8_t* d1, const uint32_t* items2,
+                                const uint8_t* d2, uint16_t* dist, hipStream_t s);
+bool build_bow_rows(const uint32_t* nodes1, const int32_t* start1, const uint32_t* items1, int nn1,
+                    const uint8_t* valid1, int n1, const uint32_t* nodes2, const int32_t* start2,
+                    const uint32_t* items2, int nn2, int n2, std::vector<BowRow>& rows, long long& npairs);
+int replay_search_by_bow(int mode, const std::vector<BowRow>& rows, const uint16_t* dist, const uint32_t* items2,
+                         const orbx_keypoint* k1, const orbx_keypoint* k2, const uint8_t* valid2, int n1, int n2,
+                         float nnratio, bool checkOri, int32_t* matches);
 hipError_t launch_window_candidates(int n1, const orbx_keypoint* k1, const uint8_t* d1, const orbx_keypoint* k2,
                                     const uint8_t* d2, const int32_t* cellStart, const int32_t* cellItems,
                                     const float* prev, float minX, float minY, float invW, float invH, float r,

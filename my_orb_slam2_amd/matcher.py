@@ -130,6 +130,34 @@ class HammingMatcher:
             "orbx_search_for_initialization")
         return n.value, out
 
+    def search_by_bow(self, keys1_un, desc1, valid1, fv1, keys2, desc2, fv2, valid2=None, nnratio=0.7,
+                      check_orientation=True):
+        """ORBmatcher::SearchByBoW. valid2 None: the KeyFrame x Frame overload (src/ORBmatcher.cc:153-293,
+        called with ORBmatcher(0.7, true) at src/Tracking.cc:840-843); matches has one entry per side-2
+        feature. valid2 given: the KeyFrame x KeyFrame overload (:532-690); one entry per side-1 feature.
+        fvK = (nodes, start, items): ascending node ids, features of node j = items[start[j]:start[j+1]].
+        Returns (nmatches, matches)."""
+        from ._lib import KEYPOINT_DTYPE
+        k1 = np.ascontiguousarray(keys1_un, dtype=KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(keys2, dtype=KEYPOINT_DTYPE)
+        d1 = np.ascontiguousarray(desc1, dtype=np.uint8)
+        d2 = np.ascontiguousarray(desc2, dtype=np.uint8)
+        v1 = np.ascontiguousarray(valid1, dtype=np.uint8)
+        v2 = None if valid2 is None else np.ascontiguousarray(valid2, dtype=np.uint8)
+        a = [np.ascontiguousarray(fv1[0], dtype=np.uint32), np.ascontiguousarray(fv1[1], dtype=np.int32),
+             np.ascontiguousarray(fv1[2], dtype=np.uint32)]
+        b = [np.ascontiguousarray(fv2[0], dtype=np.uint32), np.ascontiguousarray(fv2[1], dtype=np.int32),
+             np.ascontiguousarray(fv2[2], dtype=np.uint32)]
+        mode = 0 if v2 is None else 1
+        out = np.empty(len(k2) if mode == 0 else len(k1), dtype=np.int32)
+        n = C.c_int(0)
+        check(lib().orbx_search_by_bow(
+            self._m, mode, np_ptr(k1), np_ptr(d1), np_ptr(v1), len(k1), np_ptr(a[0]), np_ptr(a[1]), np_ptr(a[2]),
+            len(a[0]), np_ptr(k2), np_ptr(d2), None if v2 is None else np_ptr(v2), len(k2), np_ptr(b[0]),
+            np_ptr(b[1]), np_ptr(b[2]), len(b[0]), float(nnratio), 1 if check_orientation else 0, np_ptr(out),
+            C.byref(n)), "orbx_search_by_bow")
+        return n.value, out
+
     @staticmethod
     def image_bounds(cam, width, height):
         """Frame::ComputeImageBounds (src/Frame.cc:474-501) -> (minX, minY, maxX, maxY)."""

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <list>
 #include <utility>
+#include <map>
 #include <vector>
 
 namespace {
@@ -1060,5 +1061,98 @@ extern "C" int orc_search_for_initialization(const orc_keypoint* k1, const uint8
             prev[2 * i1] = k2[vnMatches12[i1]].x;
             prev[2 * i1 + 1] = k2[vnMatches12[i1]].y;
         }
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByBoW: mode 0 = (KeyFrame*, Frame&, ...) src/ORBmatcher.cc:153-293, mode 1 =
+ * (KeyFrame*, KeyFrame*, ...) :532-690. DBoW3::FeatureVector is a std::map<node id, vector<feature index>>;
+ * it is rebuilt here from the flattened form so that the walk uses the same begin / lower_bound / ++ steps. */
+extern "C" int orc_search_by_bow(int mode, const orc_keypoint* k1, const uint8_t* d1, const uint8_t* valid1, int n1,
+                                 const uint32_t* nodes1, const int32_t* start1, const uint32_t* items1, int nn1,
+                                 const orc_keypoint* k2, const uint8_t* d2, const uint8_t* valid2, int n2,
+                                 const uint32_t* nodes2, const int32_t* start2, const uint32_t* items2, int nn2,
+                                 float mfNNratio, int checkOri, int32_t* out) {
+    const int HISTO_LENGTH = 30, TH_LOW = 50;
+    typedef std::map<uint32_t, std::vector<unsigned int>> FeatureVector;
+    FeatureVector fv1, fv2;
+    for (int j = 0; j < nn1; j++) fv1[nodes1[j]].assign(items1 + start1[j], items1 + start1[j + 1]);
+    for (int j = 0; j < nn2; j++) fv2[nodes2[j]].assign(items2 + start2[j], items2 + start2[j + 1]);
+    const int nout = mode == 0 ? n2 : n1;
+    for (int i = 0; i < nout; i++) out[i] = -1;
+    std::vector<bool> vbMatched2(n2, false);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    FeatureVector::const_iterator it1 = fv1.begin(), it2 = fv2.begin(), end1 = fv1.end(), end2 = fv2.end();
+    while (it1 != end1 && it2 != end2) {
+        if (it1->first == it2->first) {
+            const std::vector<unsigned int>& v1 = it1->second;
+            const std::vector<unsigned int>& v2 = it2->second;
+            for (size_t i1 = 0; i1 < v1.size(); i1++) {
+                const unsigned int idx1 = v1[i1];
+                if (!valid1[idx1]) continue; /* no MapPoint or a bad one */
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (size_t i2 = 0; i2 < v2.size(); i2++) {
+                    const unsigned int idx2 = v2[i2];
+                    if (mode == 0) {
+                        if (out[idx2] >= 0) continue;            /* :212 vpMapPointMatches[realIdxF] */
+                    } else {
+                        if (vbMatched2[idx2] || !valid2[idx2]) continue; /* :597-601 */
+                    }
+                    const int dist = orc_hamming256(d1 + 32 * (size_t)idx1, d2 + 32 * (size_t)idx2);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = (int)idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                const bool close = mode == 0 ? (bestDist1 <= TH_LOW) : (bestDist1 < TH_LOW);
+                if (close) {
+                    if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+                        if (mode == 0) {
+                            out[bestIdx2] = (int)idx1;
+                        } else {
+                            out[idx1] = bestIdx2;
+                            vbMatched2[bestIdx2] = true;
+                        }
+                        if (checkOri) {
+                            float rot = k1[idx1].angle - k2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot / (360 * factor));
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(mode == 0 ? bestIdx2 : (int)idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            it1++;
+            it2++;
+        } else if (it1->first < it2->first) {
+            it1 = fv1.lower_bound(it2->first);
+        } else {
+            it2 = fv2.lower_bound(it1->first);
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) { /* ComputeThreeMaxima (:1652-1693) */
+            const int s = (int)rotHist[i].size();
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                out[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
     return nmatches;
 }

@@ -126,6 +126,16 @@ int   orc_search_for_initialization(const orc_keypoint* k1, const uint8_t* d1, i
                                     float minX, float minY, float maxX, float maxY, float* prev_matched,
                                     int window_size, float nnratio, int check_orientation, int32_t* matches12);
 
+/* ORBmatcher::SearchByBoW: mode 0 the (KeyFrame*, Frame&) overload (src/ORBmatcher.cc:153-293; out has n2
+ * entries = side-1 index per side-2 feature), mode 1 the (KeyFrame*, KeyFrame*) overload (:532-690; out has n1
+ * entries = side-2 index per side-1 feature). validK[i] != 0 where the feature holds a live MapPoint
+ * (valid2 unread in mode 0). Feature vectors flattened: ascending node ids, items[start[j]..start[j+1]). */
+int   orc_search_by_bow(int mode, const orc_keypoint* k1, const uint8_t* d1, const uint8_t* valid1, int n1,
+                        const uint32_t* nodes1, const int32_t* start1, const uint32_t* items1, int nn1,
+                        const orc_keypoint* k2, const uint8_t* d2, const uint8_t* valid2, int n2,
+                        const uint32_t* nodes2, const int32_t* start2, const uint32_t* items2, int nn2,
+                        float nnratio, int check_orientation, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,9 @@ def lib():
         L.orc_search_for_initialization.restype = C.c_int
         L.orc_search_for_initialization.argtypes = [_P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float, C.c_float,
                                                     C.c_float, _P, C.c_int, C.c_float, C.c_int, _P]
+        L.orc_search_by_bow.restype = C.c_int
+        L.orc_search_by_bow.argtypes = [C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int,
+                                        _P, _P, _P, C.c_int, C.c_float, C.c_int, _P]
         _LIB = L
     return _LIB
 
@@ -257,3 +260,21 @@ def search_for_initialization(k1, d1, k2, d2, bounds, prev, window=100, nnratio=
                                             bounds[2], bounds[3], ptr(prev), window, nnratio, 1 if check_ori else 0,
                                             ptr(out))
     return n, out, prev
+
+
+def search_by_bow(k1, d1, valid1, fv1, k2, d2, fv2, valid2=None, nnratio=0.7, check_ori=True):
+    """fvK = (nodes uint32 ascending, start int32, items uint32)."""
+    k1 = np.ascontiguousarray(k1, dtype=KP)
+    k2 = np.ascontiguousarray(k2, dtype=KP)
+    d1 = np.ascontiguousarray(d1, dtype=np.uint8)
+    d2 = np.ascontiguousarray(d2, dtype=np.uint8)
+    v1 = np.ascontiguousarray(valid1, dtype=np.uint8)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, dtype=np.uint8)
+    a = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32)]
+    b = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32)]
+    mode = 0 if v2 is None else 1
+    out = np.empty(len(k2) if mode == 0 else len(k1), dtype=np.int32)
+    n = lib().orc_search_by_bow(mode, ptr(k1), ptr(d1), ptr(v1), len(k1), ptr(a[0]), ptr(a[1]), ptr(a[2]), len(a[0]),
+                                ptr(k2), ptr(d2), None if v2 is None else ptr(v2), len(k2), ptr(b[0]), ptr(b[1]),
+                                ptr(b[2]), len(b[0]), nnratio, 1 if check_ori else 0, ptr(out))
+    return n, out

@@ -1,0 +1,92 @@
+"""GPU parity of orbx_search_by_bow against the oracle's ORBmatcher::SearchByBoW (both overloads)."""
+import numpy as np
+import pytest
+
+import my_orb_slam2_amd as m
+from tests import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(seed, n1, n2, n_nodes, noise_bits=20):
+    """Two feature sets that share ground-truth points. Side 2 holds noisy copies of a random subset of side 1
+    plus unrelated features; a feature's vocabulary node is a function of its ground-truth point (with a few
+    wrong assignments), so common nodes hold true pairs, near-duplicates and distractors."""
+    rng = np.random.default_rng(seed)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    # near-duplicates on side 1 make the ratio test matter
+    dup = rng.choice(n1, n1 // 10, replace=False)
+    d1[dup] = d1[rng.choice(n1, len(dup))] ^ (rng.integers(0, 256, (len(dup), 32), dtype=np.uint8) & 0x01)
+    src = rng.integers(0, n1, n2)
+    d2 = d1[src].copy()
+    flips = rng.integers(0, noise_bits + 1, n2)
+    for i in range(n2):
+        bits = rng.choice(256, flips[i], replace=False)
+        for b in bits:
+            d2[i, b >> 3] ^= 1 << (b & 7)
+    unrelated = rng.random(n2) < 0.2
+    d2[unrelated] = rng.integers(0, 256, (int(unrelated.sum()), 32), dtype=np.uint8)
+    node1 = rng.integers(0, n_nodes, n1) * 7 + 3
+    node2 = node1[src].copy()
+    wrong = rng.random(n2) < 0.1
+    node2[wrong] = rng.integers(0, n_nodes, int(wrong.sum())) * 7 + 3
+    k1 = np.zeros(n1, dtype=m.KEYPOINT_DTYPE)
+    k2 = np.zeros(n2, dtype=m.KEYPOINT_DTYPE)
+    k1["angle"] = rng.uniform(0, 360, n1).astype(np.float32)
+    # most true pairs share a rotation of about 30 degrees; the rest are spread out
+    rot = np.where(rng.random(n2) < 0.7, 30 + rng.normal(0, 4, n2), rng.uniform(0, 360, n2))
+    k2["angle"] = np.mod(k1["angle"][src] - rot, 360).astype(np.float32)
+    valid1 = (rng.random(n1) < 0.8).astype(np.uint8)
+    valid2 = (rng.random(n2) < 0.8).astype(np.uint8)
+
+    def fv(node, order_rng):
+        ids = np.unique(node)
+        items, start = [], [0]
+        for nid in ids:
+            members = np.flatnonzero(node == nid)
+            order_rng.shuffle(members)          # DBoW3 appends in feature order; any order must work
+            items.extend(members.tolist())
+            start.append(len(items))
+        return ids.astype(np.uint32), np.array(start, np.int32), np.array(items, np.uint32)
+
+    return k1, d1, valid1, fv(node1, rng), k2, d2, valid2, fv(node2, rng)
+
+
+@pytest.mark.parametrize("seed,n1,n2,n_nodes", [(1, 1000, 1200, 120), (2, 2000, 2000, 40), (3, 300, 50, 500),
+                                                 (4, 1500, 1500, 3)])
+def test_search_by_bow_both_overloads(seed, n1, n2, n_nodes):
+    k1, d1, v1, fv1, k2, d2, v2, fv2 = make_case(seed, n1, n2, n_nodes)
+    hm = m.HammingMatcher(0)
+    total = 0
+    for check_ori in (True, False):
+        for ratio in (0.7, 0.9):
+            want_n, want = orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, None, ratio, check_ori)
+            n, got = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, None, ratio, check_ori)
+            assert n == want_n and np.array_equal(got, want)
+            total += n
+            want_n, want = orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, v2, ratio, check_ori)
+            n, got = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, v2, ratio, check_ori)
+            assert n == want_n and np.array_equal(got, want)
+            total += n
+    assert total > 0            # the case is not vacuous
+
+
+def test_search_by_bow_edges():
+    k1, d1, v1, fv1, k2, d2, v2, fv2 = make_case(5, 200, 200, 20)
+    hm = m.HammingMatcher(0)
+    empty = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.uint32))
+    n, got = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, empty)
+    assert n == 0 and (got == -1).all() and len(got) == len(k2)
+    n, got = hm.search_by_bow(k1, d1, np.zeros_like(v1), fv1, k2, d2, fv2)       # no live map point
+    assert n == 0 and (got == -1).all()
+    # disjoint node ids
+    fv2b = (fv2[0] + 1, fv2[1], fv2[2])
+    n, got = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2b, v2)
+    assert n == 0 and (got == -1).all() and len(got) == len(k1)
+    # an index outside the feature set is rejected, as is an unsorted node list
+    bad = (fv2[0], fv2[1], fv2[2].copy())
+    bad[2][0] = len(k2)
+    with pytest.raises(m.OrbxError):
+        hm.search_by_bow(k1, d1, v1, fv1, k2, d2, bad)
+    with pytest.raises(m.OrbxError):
+        hm.search_by_bow(k1, d1, v1, (fv1[0][::-1].copy(), fv1[1], fv1[2]), k2, d2, fv2)

@@ -332,3 +332,96 @@ def test_assign_grid_known_answers():
     # round(x * 64/752): 0 -> 0; 751.9 -> 64 (outside, dropped); 376 -> 32; -30 -> -3 (dropped)
     assert start[-1] == 3 and list(items) == [0, 2, 3]
     assert start[32 * 48 + 24 + 1] - start[32 * 48 + 24] == 2
+
+
+def test_search_by_bow_against_python_restatement():
+    """orc_search_by_bow against a direct Python transcription of src/ORBmatcher.cc:153-293 / :532-690 on a
+    small case (dict of node -> list, bisect for lower_bound)."""
+    import bisect
+    from tests.test_gpu_search_bow import make_case
+    k1, d1, v1, fv1, k2, d2, v2, fv2 = make_case(11, 150, 160, 12, noise_bits=30)
+    ham = lambda a, b: int(np.unpackbits(a ^ b).sum())
+
+    def restate(mode, ratio, check_ori):
+        keys1, keys2 = list(fv1[0]), list(fv2[0])
+        lst1 = {int(n): list(fv1[2][fv1[1][j]:fv1[1][j + 1]]) for j, n in enumerate(keys1)}
+        lst2 = {int(n): list(fv2[2][fv2[1][j]:fv2[1][j + 1]]) for j, n in enumerate(keys2)}
+        out = [-1] * (len(k2) if mode == 0 else len(k1))
+        matched2 = [False] * len(k2)
+        hist = [[] for _ in range(30)]
+        factor = np.float32(1.0) / np.float32(30)
+        a = b = 0
+        n = 0
+        while a < len(keys1) and b < len(keys2):
+            if keys1[a] == keys2[b]:
+                for idx1 in lst1[int(keys1[a])]:
+                    if not v1[idx1]:
+                        continue
+                    best1, best2, bidx = 256, 256, -1
+                    for idx2 in lst2[int(keys2[b])]:
+                        if mode == 0 and out[idx2] >= 0:
+                            continue
+                        if mode == 1 and (matched2[idx2] or not v2[idx2]):
+                            continue
+                        dist = ham(d1[idx1], d2[idx2])
+                        if dist < best1:
+                            best2, best1, bidx = best1, dist, int(idx2)
+                        elif dist < best2:
+                            best2 = dist
+                    ok = best1 <= 50 if mode == 0 else best1 < 50
+                    if ok and np.float32(best1) < np.float32(ratio) * np.float32(best2):
+                        if mode == 0:
+                            out[bidx] = int(idx1)
+                        else:
+                            out[idx1] = bidx
+                            matched2[bidx] = True
+                        if check_ori:
+                            rot = np.float32(k1["angle"][idx1]) - np.float32(k2["angle"][bidx])
+                            if rot < 0:
+                                rot = np.float32(rot + np.float32(360.0))
+                            q = float(np.float32(rot / (np.float32(360) * factor)))
+                            bin_ = int(np.floor(q + 0.5)) if q >= 0 else int(np.ceil(q - 0.5))
+                            if bin_ == 30:
+                                bin_ = 0
+                            hist[bin_].append(bidx if mode == 0 else int(idx1))
+                        n += 1
+                a += 1
+                b += 1
+            elif keys1[a] < keys2[b]:
+                a = bisect.bisect_left(keys1, keys2[b])
+            else:
+                b = bisect.bisect_left(keys2, keys1[a])
+        if check_ori:
+            sizes = [len(h) for h in hist]
+            m1 = m2 = m3 = 0
+            i1 = i2 = i3 = -1
+            for i, s in enumerate(sizes):
+                if s > m1:
+                    m3, m2, m1 = m2, m1, s
+                    i3, i2, i1 = i2, i1, i
+                elif s > m2:
+                    m3, m2 = m2, s
+                    i3, i2 = i2, i
+                elif s > m3:
+                    m3, i3 = s, i
+            if m2 < np.float32(0.1) * np.float32(m1):
+                i2 = i3 = -1
+            elif m3 < np.float32(0.1) * np.float32(m1):
+                i3 = -1
+            for i in range(30):
+                if i in (i1, i2, i3):
+                    continue
+                for e in hist[i]:
+                    out[e] = -1
+                    n -= 1
+        return n, np.array(out, np.int32)
+
+    seen = 0
+    for mode in (0, 1):
+        for ratio in (0.7, 0.9):
+            for check_ori in (False, True):
+                want_n, want = restate(mode, ratio, check_ori)
+                got_n, got = orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, v2 if mode else None, ratio, check_ori)
+                assert got_n == want_n and np.array_equal(got, want)
+                seen += want_n
+    assert seen > 20
