@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Secondary workloads of BASELINE.json on one rank's GPU (bench.py stays on configs[1]):
+
+  stereo   configs[2]: pairs of 752x480 frames, nFeatures 1200: left + right extraction and the whole of
+           Frame::ComputeStereoMatches on the device -> stereo pairs/s
+  hd       configs[3]: 1920x1080 frames, nFeatures 2000 -> frames/s
+  knn      configs[4] scaled to one GPU's share: 65536 queries x 4 M database rows per rank, database sharded
+           over the ranks, one all-gather + exact merge (RCCL when launched with torchrun) -> pairs/s
+
+    python tools/bench_configs.py [stereo] [hd] [knn]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_configs.py knn
+
+Prints one JSON object per workload (rank 0); every rank works on its own frames / database shard.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(torch, dist, world, fn, steps, warmup):
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import my_orb_slam2_amd as m
+    from my_orb_slam2_amd.sharding import ShardedHammingMatcher
+
+    which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["stereo", "hd", "knn"]
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    if "stereo" in which:
+        B, W, H, NF = 128, 752, 480, 1200
+        exl = m.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B)
+        exr = m.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B)
+        cap = exl.capacity
+        left = torch.from_numpy(m.synth_batch(rank * B, B, W, H)).cuda()
+        right = torch.from_numpy(m.synth_batch(rank * B, B, W, H, right_view=True)).cuda()
+
+        def alloc():
+            return (torch.empty((B, cap, 7), dtype=torch.float32, device="cuda"),
+                    torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                    torch.zeros(B, dtype=torch.int32, device="cuda"))
+        kl, dl, nl = alloc()
+        kr, dr, nr = alloc()
+        ur = torch.empty((B, cap), dtype=torch.float32, device="cuda")
+        z = torch.empty((B, cap), dtype=torch.float32, device="cuda")
+        hm = m.HammingMatcher(local)
+        bf, b = 47.90639384423901, 47.90639384423901 / 435.2046959714599     # EuRoC stereo: Camera.bf, bf / fx
+
+        def step(i):
+            exl.extract_batch_device(left, kl, dl, nl)
+            exr.extract_batch_device(right, kr, dr, nr)
+            exl.synchronize()      # the matcher's stream reads both contexts' outputs and pyramids
+            exr.synchronize()
+            hm.compute_stereo_matches_device(exl, exr, kl, dl, nl, kr, dr, nr, bf, b, ur, z)
+            hm.synchronize()
+        steps = 16
+        dt = timed(torch, dist, world, step, steps, 2)
+        if rank == 0:
+            matched = float((ur >= 0).sum().item()) / B
+            print(json.dumps({"workload": "configs[2] stereo pairs, 752x480, nFeatures 1200, extraction x2 + ComputeStereoMatches",
+                              "value": round(world * B * steps / dt, 1), "unit": "stereo pairs/s", "n_gpus": world,
+                              "pairs_per_step_per_gpu": B, "ms_per_step": round(dt / steps * 1e3, 3),
+                              "mean_stereo_matches_per_pair": round(matched, 1), "collective": "none"}))
+        del exl, exr
+
+    if "hd" in which:
+        B, W, H, NF = 64, 1920, 1080, 2000
+        ex = [m.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B) for _ in range(2)]
+        cap = ex[0].capacity
+        frames = torch.from_numpy(m.synth_batch(rank * B, B, W, H)).cuda()
+        outs = [(torch.empty((B, cap, 7), dtype=torch.float32, device="cuda"),
+                 torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                 torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(2)]
+
+        def step(i):
+            k, d, c = outs[i % 2]
+            ex[i % 2].extract_batch_device(frames, k, d, c)
+        steps = 16
+        dt = timed(torch, dist, world, step, steps, 2)
+        if rank == 0:
+            print(json.dumps({"workload": "configs[3] 1920x1080, nFeatures 2000, 8 levels", "n_gpus": world,
+                              "value": round(world * B * steps / dt, 1), "unit": "frames/s",
+                              "frames_per_step_per_gpu": B, "ms_per_step": round(dt / steps * 1e3, 3),
+                              "mean_keypoints_per_frame": round(float(outs[0][2].float().mean().item()), 1),
+                              "collective": "none"}))
+        del ex
+
+    if "knn" in which:
+        nq, shard = 65536, 4 * 1024 * 1024
+        g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+        db = torch.randint(0, 256, (shard, 32), dtype=torch.uint8, device="cuda", generator=g)
+        gq = torch.Generator(device="cuda").manual_seed(99)      # the same queries on every rank
+        q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device="cuda", generator=gq)
+        sm = ShardedHammingMatcher(db, rank * shard, device=local)
+        res = []
+
+        def step(i):
+            res[:] = [sm.knn2(q)]
+        steps = 3
+        dt = timed(torch, dist, world, step, steps, 1)
+        if rank == 0:
+            print(json.dumps({"workload": "configs[4] scaled: 65536 queries x %d database rows (%d per GPU), top-2 + merge"
+                                          % (world * shard, shard), "n_gpus": world,
+                              "value": nq * world * shard * steps / dt, "unit": "Hamming pairs/s",
+                              "ms_per_step": round(dt / steps * 1e3, 3),
+                              "collective": "all_gather of 3 x nq int per rank" if world > 1 else "none"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
