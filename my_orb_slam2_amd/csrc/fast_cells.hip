@@ -271,15 +271,20 @@ hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nfram
     dim3 grid(nframes, (g.totalCells + kCellsPerBlock - 1) / kCellsPerBlock, 1), block(64 * kCellsPerBlock, 1, 1);
     const bool aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
     const bool small = g.tilePitch == 48;
-    if (aligned && small)
-        hipLaunchKernelGGL((fast_cells_kernel<true, 48>), grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
-    else if (aligned)
-        hipLaunchKernelGGL((fast_cells_kernel<true, 80>), grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
-    else if (small)
-        hipLaunchKernelGGL((fast_cells_kernel<false, 48>), grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
-    else
-        hipLaunchKernelGGL((fast_cells_kernel<false, 80>), grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
-    return hipGetLastError();
+    // the widest possible cells (59 x 59 px at pitch 80) need a little over the default 64 KB of dynamic LDS
+    auto launch = [&](auto kernel) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
+        return hipGetLastError();
+    };
+    if (aligned && small) return launch(fast_cells_kernel<true, 48>);
+    if (aligned) return launch(fast_cells_kernel<true, 80>);
+    if (small) return launch(fast_cells_kernel<false, 48>);
+    return launch(fast_cells_kernel<false, 80>);
 }
 
 }  // namespace orbx

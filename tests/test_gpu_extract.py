@@ -94,10 +94,18 @@ def test_getters_match_reference_tables():
 
 
 @pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (321, 243, 500), (1241, 376, 2000), (1920, 1080, 2000),
-                                    (97, 80, 300)])
+                                    (97, 80, 300), (91, 91, 100), (150, 91, 200), (91, 130, 200)])
 def test_other_sizes(w, h, nf):
     gpu, cpu = make(nfeatures=nf, w=w, h=h)
     compare_frame(gpu, cpu, m.synth_frame(11, w, h))
+
+
+def test_portrait_level_that_the_reference_cannot_split():
+    """91x200: level 0 is 59 x 168 px inside the border, so DistributeOctTree's nIni = round(59/168) = 0
+    (src/ORBextractor.cc:537) and the reference divides by zero; both sides return no keypoints for such a
+    level (the GPU does not even scan it), and the remaining levels still agree."""
+    gpu, cpu = make(nfeatures=200, w=91, h=200)
+    compare_frame(gpu, cpu, m.synth_frame(11, 91, 200), stages=False)
 
 
 def test_other_parameters():
