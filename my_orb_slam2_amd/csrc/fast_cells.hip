@@ -128,14 +128,16 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     // ---- 1. stage the cell in LDS ----
     uint8_t* tile = smem;
     constexpr int pitch = PITCH;
-    int xo;
+    // Tile column c holds image column iniX - 1 + c, so the first scanned pixel (iniX + 3) sits at tile column 4
+    // and groups of four scanned pixels are whole LDS dwords.
+    constexpr int xo = 1;
     if (ALIGNED4) {
-        const int xa = iniX & ~3;
-        const int ndw = (maxX - xa + 3) >> 2;
-        xo = iniX - xa;
+        const int xa = (iniX - 1) & ~3;
+        const uint32_t shift = (uint32_t)((iniX - 1) & 3);
+        const int ndw = (maxX - iniX + 1 + 3) >> 2;
         // A row of the tile is at most PITCH/4 dwords: 16 lanes (four rows per step) or 32 lanes (two rows)
-        // take one row each, so stepping to the next rows is one add on the source pointer and a constant on
-        // the LDS side. Ten loads are in flight before the first LDS store.
+        // take one row each, so stepping to the next rows is a constant on the LDS side. A tile dword is cut
+        // from the two aligned dwords around it (v_alignbyte); both stay left of column maxX + 6 <= w - 10.
         constexpr int kRowLanes = PITCH <= 64 ? 16 : 32, kRowsPerStep = 64 / kRowLanes;
         constexpr int kBatch = kTileRowBatch / kRowsPerStep;
         const int td = lane & (kRowLanes - 1), tr = lane / kRowLanes;
@@ -146,24 +148,26 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
         const uint32_t col = (uint32_t)(xa + td * 4), stride32 = (uint32_t)rowStride;
         if (td < ndw) {
             for (int r0 = 0; r0 < th; r0 += kTileRowBatch) {
-                uint32_t v[kBatch];
+                uint32_t lo[kBatch], hi[kBatch];
 #pragma unroll
                 for (int q = 0; q < kBatch; q++) {
                     const uint32_t row = (uint32_t)(iniY + min(r0 + tr + kRowsPerStep * q, th - 1));
-                    v[q] = *reinterpret_cast<const uint32_t*>(img + (size_t)(__umul24(row, stride32) + col));
+                    const uint8_t* src = img + (size_t)(__umul24(row, stride32) + col);
+                    lo[q] = reinterpret_cast<const uint32_t*>(src)[0];
+                    hi[q] = reinterpret_cast<const uint32_t*>(src)[1];
                 }
 #pragma unroll
-                for (int q = 0; q < kBatch; q++) tile32[(r0 + kRowsPerStep * q) * (PITCH / 4)] = v[q];
+                for (int q = 0; q < kBatch; q++)
+                    tile32[(r0 + kRowsPerStep * q) * (PITCH / 4)] = __builtin_amdgcn_alignbyte(hi[q], lo[q], shift);
             }
         }
     } else {
-        const int tw = maxX - iniX;
-        xo = 0;
+        const int tw = maxX - iniX + 1;
         const int recip = (65536 + tw - 1) / tw;
         for (int i = lane; i < tw * th; i += 64) {
             const int y = div_small(i, recip);
             const int x = i - y * tw;
-            tile[y * pitch + x] = img[(long long)(iniY + y) * rowStride + iniX + x];
+            tile[y * pitch + x] = img[(long long)(iniY + y) * rowStride + iniX - 1 + x];
         }
     }
     uint8_t* score = smem + g.maxTileBytes;            // (sw+2) x (sh+2), zero ring
@@ -177,34 +181,56 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     wave_sync();
 
     // ---- 2. cheap test at the low threshold, queue survivors in row-major order ----
-    // Lanes map to whole rows: two rows of 32 lanes when the scan is at most 32 px wide, else one row of
-    // 64, so stepping to the next rows is one add on the LDS address. A queue entry is (y << 8) | x.
+    // A lane tests four horizontally adjacent pixels per step from five LDS dwords (the row itself: the group,
+    // its left and right neighbours; rows -3 and +3: the group), every byte picked by an SDWA operand select.
+    // 8 lanes span a scan of up to 32 px (8 rows per step), 16 lanes a wider one (4 rows per step).
+    // A queue entry is (y << 8) | x.
     const int tlow = min(iniTh, minTh);
-    const bool narrow = sw <= 32;
-    const int rowLanes = narrow ? 32 : 64, rowsPerIter = narrow ? 2 : 1;
-    const int lx = lane & (rowLanes - 1), ly = narrow ? lane >> 5 : 0;
+    const bool narrow = sw <= 32;                      // cells are < 60 px wide (width / floor(width / 30))
+    const int rowsPerIter = narrow ? 8 : 4;
+    const int gx = narrow ? lane & 7 : lane & 15, ly = narrow ? lane >> 3 : lane >> 4;
     int nq = 0;
     {
-        const bool inRow = lx < sw;                    // cells are < 60 px wide (width / floor(width / 30))
-        int yx = (ly << 8) | lx;
+        constexpr int P4 = PITCH / 4;
+        unsigned long long xm[4];                      // lanes whose pixel j is inside the scan
+#pragma unroll
+        for (int j = 0; j < 4; j++) xm[j] = __builtin_amdgcn_ballot_w64(4 * gx + j < sw);
+        int yx = (ly << 8) | (4 * gx);
         const int yxEnd = sh << 8;
-        const uint8_t* p = tile + (ly + 3) * pitch + xo + lx + 3;
+        const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile) + (ly + 3) * P4 + gx;
         for (int y0 = 0; y0 < sh; y0 += rowsPerIter) {
-            const int v = p[0];
-            // circle pixel k and its antipode k+8: a run of 9 holds at least one of each pair
-            const int p0 = p[3 * pitch], p8 = p[-3 * pitch];
-            const int p4 = p[3], p12 = p[-3];
-            // all pairs have a pixel < v-t  <=>  max over pairs of min < v-t; likewise for > v+t. Two of the
-            // eight pairs reject ~85% of the pixels; what passes goes straight to the exact strength.
-            const int mnmax = max(min(p0, p8), min(p4, p12));
-            const int mxmin = min(max(p0, p8), max(p4, p12));
-            // (bitwise, not short-circuit: the whole test stays branch-free lane-mask arithmetic)
-            const bool pass = ((mnmax < v - tlow) | (mxmin > v + tlow)) & inRow & (yx < yxEnd);
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-            if (pass) queue[nq + prefix_count(m)] = (uint16_t)yx;
-            nq += __popcll(m);
+            const uint32_t A = t32[0], B = t32[1], C = t32[2], U = t32[1 - 3 * P4], D = t32[1 + 3 * P4];
+            const unsigned long long ym = __builtin_amdgcn_ballot_w64(yx < yxEnd);
+            unsigned long long m[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int v = (int)((B >> (8 * j)) & 0xff);
+                // circle pixel k and its antipode k+8: a run of 9 holds at least one of each pair
+                const int p8 = (int)((U >> (8 * j)) & 0xff), p0 = (int)((D >> (8 * j)) & 0xff);
+                const int p12 = (int)(((j < 3 ? A : B) >> (8 * ((j + 1) & 3))) & 0xff);
+                const int p4 = (int)(((j == 0 ? B : C) >> (8 * ((j + 3) & 3))) & 0xff);
+                // all pairs have a pixel < v-t  <=>  max over pairs of min < v-t; likewise for > v+t. Two of the
+                // eight pairs reject ~85% of the pixels; what passes goes straight to the exact strength.
+                const int mnmax = max(min(p0, p8), min(p4, p12));
+                const int mxmin = min(max(p0, p8), max(p4, p12));
+                // compare straight into lane masks (40 = signed <, 38 = signed >); the rest is scalar
+                m[j] = (__builtin_amdgcn_sicmp(mnmax, v - tlow, 40) | __builtin_amdgcn_sicmp(mxmin, v + tlow, 38)) &
+                       xm[j] & ym;
+            }
+            // row-major rank: everything queued by lower lanes, then this lane's own earlier pixels
+            int pos = nq;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[j], pos));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool pass = __builtin_amdgcn_inverse_ballot_w64(m[j]);
+                if (pass) queue[pos] = (uint16_t)(yx + j);
+                pos += pass;
+                nq += __popcll(m[j]);
+            }
             yx += rowsPerIter << 8;
-            p += rowsPerIter * pitch;
+            t32 += rowsPerIter * P4;
         }
     }
     wave_sync();
