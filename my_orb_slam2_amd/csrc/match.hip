@@ -6,7 +6,8 @@
 // kNN kernel: one thread owns one query descriptor in 8 VGPRs. All 64 lanes of a wave walk the same
 // database row at the same time, so the row address is wave-uniform and the row arrives through
 // scalar loads into SGPRs; one pair costs 8 v_xor_b32 + 8 v_bcnt_u32_b32 (the popcount
-// instruction adds its accumulator for free) and three more VALU ops for the running best two.
+// instruction adds its accumulator for free); the three VALU ops that maintain the running best two
+// are skipped for groups of rows that cannot change them.
 // The two best are kept as 32-bit keys (distance << 23 | row offset inside the chunk): taking
 // min / median-of-3 on keys reproduces the reference's strict `<` updates, i.e. the lowest row
 // index wins ties for the best and the second best is the second order statistic of the distances.
@@ -26,6 +27,14 @@ struct Partial {       // result of one query over one database chunk
     int64_t idx;       // global row of d1, -1 if none
 };
 
+// v_bcnt_u32_b32 adds its second operand for free; written out so that the eight counts of a pair stay one
+// accumulate chain (left to itself the compiler splits the chain and pays three extra adds per pair).
+__device__ __forceinline__ int bcnt_acc(uint32_t x, int acc) {
+    int r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
     return max(min(a, b), min(max(a, b), c));
 }
@@ -43,21 +52,43 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn2_kernel(const uint4* __r
     const int rows = (int)min(chunkRows, ndb - j0);
     const uint4* __restrict__ base = db + 2 * j0;
     unsigned k1 = kEmptyKey, k2 = kEmptyKey;
-#pragma unroll 8
-    for (int j = 0; j < rows; j++) {
-        const uint4 ra = base[2 * j], rb = base[2 * j + 1];   // wave-uniform address: scalar loads
-        int d = __popc(qa.x ^ ra.x);
-        d += __popc(qa.y ^ ra.y);
-        d += __popc(qa.z ^ ra.z);
-        d += __popc(qa.w ^ ra.w);
-        d += __popc(qb.x ^ rb.x);
-        d += __popc(qb.y ^ rb.y);
-        d += __popc(qb.z ^ rb.z);
-        d += __popc(qb.w ^ rb.w);
+    // Rows go four at a time. A row can only change the best two if its distance is below the current
+    // second best (its key carries a larger row offset than any key seen before), so the key updates of a
+    // group are skipped when no lane of the wave has such a row: after the first few hundred rows of a chunk
+    // that is almost always, and a pair costs its 16 xor / popcount instructions plus 3/4 of one more.
+    unsigned thr = kEmptyKey >> 23;             // distance of k2 (511 while there is no second best)
+    const int zero = 0;
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    const u32x8* __restrict__ row8 = reinterpret_cast<const u32x8*>(base);   // one s_load_dwordx8 per row
+    auto distance = [&](int r) {
+        const u32x8 w = row8[r];                                             // wave-uniform address
+        int d = bcnt_acc(qa.x ^ w[0], zero);
+        d = bcnt_acc(qa.y ^ w[1], d);
+        d = bcnt_acc(qa.z ^ w[2], d);
+        d = bcnt_acc(qa.w ^ w[3], d);
+        d = bcnt_acc(qb.x ^ w[4], d);
+        d = bcnt_acc(qb.y ^ w[5], d);
+        d = bcnt_acc(qb.z ^ w[6], d);
+        return bcnt_acc(qb.w ^ w[7], d);
+    };
+    auto update = [&](int d, int j) {
         const unsigned key = ((unsigned)d << 23) | (unsigned)j;
         k2 = umed3(k1, k2, key);   // k1 <= k2 always holds
         k1 = min(k1, key);
+    };
+    int j = 0;
+    for (; j + 4 <= rows; j += 4) {
+        int d[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) d[i] = distance(j + i);
+        const unsigned dmin = (unsigned)min(min(d[0], d[1]), min(d[2], d[3]));
+        if (__builtin_amdgcn_ballot_w64(dmin < thr) != 0) {      // wave-uniform branch
+#pragma unroll
+            for (int i = 0; i < 4; i++) update(d[i], j + i);
+            thr = k2 >> 23;
+        }
     }
+    for (; j < rows; j++) update(distance(j), j);
     if (qi >= nq) return;
     Partial p;
     p.d1 = k1 == kEmptyKey ? INT32_MAX : (int32_t)(k1 >> 23);

@@ -46,6 +46,28 @@ def test_knn2_ties_and_duplicates():
     assert np.all(idx < 50)                                # lowest index wins
 
 
+def test_knn2_monotone_orders_and_short_tails():
+    """Database rows ordered so that the best two change at every row (distances falling), never after the
+    first two (rising), or stay equal; lengths around the kernel's row grouping."""
+    rng = np.random.default_rng(21)
+    q = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    target = q[0].copy()
+    rows = []
+    for nbits in range(0, 250):                            # row k differs from q[0] in exactly k bits
+        r = target.copy()
+        for b in range(nbits):
+            r[b // 8] ^= np.uint8(1 << (b % 8))
+        rows.append(r)
+    rising = np.stack(rows)
+    hm = m.HammingMatcher()
+    for db in (rising, rising[::-1].copy(), np.repeat(rising[40:41], 37, axis=0)):
+        for n in (len(db), 2, 3, 4, 5, 6, 7, 9, 37):
+            part = np.ascontiguousarray(db[:n])
+            idx, d1, d2 = hm.knn2(q, part)
+            oi, o1, o2 = orc.knn2(q, part)
+            assert np.array_equal(idx, oi) and np.array_equal(d1, o1) and np.array_equal(d2, o2)
+
+
 def test_scalar_distance():
     rng = np.random.default_rng(10)
     for _ in range(50):
