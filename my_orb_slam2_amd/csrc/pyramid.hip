@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void pyr_resize_dword_kernel(const uint8_t* __
                                                                int sw, int sh, uint8_t* __restrict__ dstBase,
                                                                long long dstRowStride, long long dstFrameStride,
                                                                int dw, int dh, ResizeTab tab) {
-    typedef short s2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const int f = blockIdx.x;                               // frame-fastest grid: one frame per XCD
     const int x4 = (blockIdx.y * 64 + threadIdx.x) * 4;
     const int wy = __builtin_amdgcn_readfirstlane(threadIdx.y);
@@ -79,28 +79,51 @@ __global__ __launch_bounds__(256) void pyr_resize_dword_kernel(const uint8_t* __
     const int lastDw = ((sw + 3) >> 2) - 1;
     const int q0 = sx0 >> 2;
     const uint32_t sh8 = (uint32_t)(sx0 & 3);
-    const int i0 = min(q0, lastDw), i1 = min(q0 + 1, lastDw), i2 = min(q0 + 2, lastDw);
+    // Source rows are read through a buffer resource: the row offset is scalar, the three dword offsets inside
+    // the row are this lane's constants, so a load needs no address arithmetic at all.
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (int)((long long)sh * srcRowStride), 0x00027000);
+    const int o0 = 4 * min(q0, lastDw), o1 = 4 * min(q0 + 1, lastDw), o2 = 4 * min(q0 + 2, lastDw);
 
-    // horizontal pass of one source row for this thread's four columns
-    auto hrow = [&](int sy, int (&h)[4]) {
-        const uint32_t* R = reinterpret_cast<const uint32_t*>(src + (long long)sy * srcRowStride);
-        const uint32_t u0 = R[i0], u1 = R[i1], u2 = R[i2];
+    // horizontal pass of one source row for this thread's four columns: (S[sx]*a0 + S[sx+1]*a1) >> 4.
+    // The weights are never negative (they are (1-f)*2048 and f*2048), so the unsigned dot product is exact.
+    auto hrow = [&](int sy, uint32_t (&h)[4]) {
+        const int rowOff = sy * (int)srcRowStride;                          // wave-uniform; a level is < 2^31 bytes
+        const uint32_t u0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, o0, rowOff, 0),
+                       u1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, o1, rowOff, 0),
+                       u2 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, o2, rowOff, 0);
         // 8-byte window starting at source column sx0 (bytes past the row end only meet zero weights)
         const uint32_t w0 = __builtin_amdgcn_alignbyte(u1, u0, sh8), w1 = __builtin_amdgcn_alignbyte(u2, u1, sh8);
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            h[k] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2, __builtin_amdgcn_perm(w1, w0, sel[k])),
-                                          __builtin_bit_cast(s2, aa[k]), 0, false);
+            h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(w1, w0, sel[k])),
+                                          __builtin_bit_cast(us2, aa[k]), 0u, false) >> 4;
+    };
+    // vertical pass + store of one destination row from the sums of its two source rows
+    auto vrow = [&](int dy, uint32_t bb, const uint32_t (&a)[4], const uint32_t (&b)[4]) {
+        const uint32_t b0 = bb << 16, b1 = bb & 0xFFFF0000u;               // weights * 65536 (both <= 2048)
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            // ((b0 * h0) >> 16) + ((b1 * h1) >> 16) + 2: the high half of (b << 16) * h is that shifted product.
+            // The sum >> 2 never leaves [0, 255] (a0 + a1, b0 + b1 <= 2049, weights >= 0), so v < 1024.
+            v[k] = __umulhi(b0, a[k]) + __umulhi(b1, b[k]) + 2u;
+        // two sums per dword, one shift for both, then bytes 0 and 2 of each (byte 1 holds the shifted-out bits)
+        const uint32_t p01 = (v[0] | (v[1] << 16)) >> 2, p23 = (v[2] | (v[3] << 16)) >> 2;
+        *reinterpret_cast<uint32_t*>(dst + (long long)dy * dstRowStride) = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
     };
 
+    // Consecutive destination rows usually share a source row (the lower row of one is the upper row of the
+    // next); its sums stay in hb.
     int cachedSy = -1;       // source row whose sums sit in hb
-    int ha[4], hb[4] = {0, 0, 0, 0};
+    uint32_t ha[4], hb[4] = {0, 0, 0, 0};
     const int dyEnd = min(dyBegin + kRowsPerThread, dh);
+    const uint32_t* beta2 = reinterpret_cast<const uint32_t*>(tab.ibeta);   // (b0, b1) of a row as one dword
     for (int dy = dyBegin; dy < dyEnd; dy++) {
         int sy0 = tab.yofs[dy], sy1 = sy0 + 1;
         sy0 = min(max(sy0, 0), sh - 1);
         sy1 = min(max(sy1, 0), sh - 1);
-        const int b0 = tab.ibeta[2 * dy], b1 = tab.ibeta[2 * dy + 1];
+        const uint32_t bb = beta2[dy];
         if (sy0 == cachedSy) {
 #pragma unroll
             for (int k = 0; k < 4; k++) ha[k] = hb[k];
@@ -114,14 +137,7 @@ __global__ __launch_bounds__(256) void pyr_resize_dword_kernel(const uint8_t* __
             for (int k = 0; k < 4; k++) hb[k] = ha[k];
         }
         cachedSy = sy1;
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            // never leaves [0, 255]: the weights are non-negative and a0 + a1, b0 + b1 <= 2049
-            const int v = (((b0 * (ha[k] >> 4)) >> 16) + ((b1 * (hb[k] >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)v << (8 * k);
-        }
-        *reinterpret_cast<uint32_t*>(dst + (long long)dy * dstRowStride) = packed;
+        vrow(dy, bb, ha, hb);
     }
 }
 
