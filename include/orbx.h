@@ -113,6 +113,10 @@ int orbx_extract_batch(orbx_ctx* ctx, const uint8_t* images, int nframes, int wi
                        size_t row_stride, size_t frame_stride, orbx_keypoint* keypoints,
                        uint8_t* descriptors, int cap, int32_t* counts);
 int orbx_synchronize(orbx_ctx* ctx);
+/* The context's own stream (a hipStream_t), for callers that order their work against the asynchronous
+ * calls above (events, or an allocator that must not recycle a buffer still being read). The reference
+ * has no counterpart: its operator() returns when the work is done (src/ORBextractor.cc:1035-1097). */
+int orbx_get_stream(orbx_ctx* ctx, void** stream);
 
 /* Stage timing. The reference has no profiler; its examples only wrap std::chrono around Track*
  * (orb_slam2_mono_example/mono_euroc.cc:96-105). With profiling enabled every batched call records
@@ -191,6 +195,8 @@ int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* left, orbx_ctx
                                        const orbx_keypoint* d_kr, const uint8_t* d_dr, const int32_t* d_nr,
                                        float bf, float b, float* d_uright, float* d_depth, void* stream);
 int orbx_matcher_synchronize(orbx_matcher* m);
+/* The matcher's own stream (a hipStream_t); see orbx_get_stream. */
+int orbx_matcher_get_stream(orbx_matcher* m, void** stream);
 
 /* ---- the step after extraction: undistort + grid ---------------------------------------------- */
 

@@ -79,6 +79,8 @@ SIGNATURES = {
     "orbx_compute_stereo_matches_device": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P,
                                                      C.c_float, C.c_float, _P, _P, _P]),
     "orbx_matcher_synchronize": (C.c_int, [_P]),
+    "orbx_matcher_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
+    "orbx_get_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "orbx_search_for_initialization": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, C.c_float, C.c_float,
                                                  C.c_float, C.c_float, _P, C.c_int, C.c_float, C.c_int, _P,
                                                  C.POINTER(C.c_int)]),

@@ -353,6 +353,17 @@ extern "C" int orbx_extract(orbx_ctx* c, const uint8_t* image, int width, int he
     return ORBX_OK;
 }
 
+extern "C" int orbx_get_stream(orbx_ctx* c, void** stream) {
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!stream) {
+        set_error("orbx_get_stream: null argument");
+        return ORBX_ERR_INVALID;
+    }
+    *stream = c->stream;
+    return ORBX_OK;
+}
+
 extern "C" int orbx_synchronize(orbx_ctx* c) {
     int rc = check_ctx(c);
     if (rc) return rc;
@@ -581,6 +592,15 @@ extern "C" void orbx_matcher_destroy(orbx_matcher* m) {
     if (m->scale) (void)hipFree(m->scale);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
+}
+
+extern "C" int orbx_matcher_get_stream(orbx_matcher* m, void** stream) {
+    if (!m || !stream) {
+        set_error("orbx_matcher_get_stream: null argument");
+        return ORBX_ERR_INVALID;
+    }
+    *stream = m->stream;
+    return ORBX_OK;
 }
 
 extern "C" int orbx_matcher_synchronize(orbx_matcher* m) {

@@ -3,6 +3,7 @@
 Same constructor arguments, same getters, same call: extractor(image, mask) -> keypoints,
 descriptors.  All computation happens in liborbx.so on the GPU.
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -29,9 +30,15 @@ class ORBextractor:
         self.device = int(device)
         self._capacity = lib().orbx_keypoint_capacity(self._ctx)
         self._last_shape = None
+        self._ext_stream = None
+        self._inflight = collections.deque()
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
+            if self._inflight:
+                lib().orbx_synchronize(self._ctx)
+                self._inflight.clear()
+            self._ext_stream = None
             lib().orbx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -130,9 +137,28 @@ class ORBextractor:
                                               C.c_void_p(d_descriptors.data_ptr()), cap,
                                               C.c_void_p(d_counts.data_ptr()), sp), "orbx_extract_batch_device")
         self._last_shape = (b, h, w)
+        if not stream:
+            # The work runs on the context's stream, which torch's allocator does not know: a tensor dropped
+            # right after this call could be handed out again while the kernels still use it. Keep the
+            # tensors referenced until an event recorded behind the call has completed.
+            import torch
+            ev = torch.cuda.Event()
+            ev.record(self._torch_stream())
+            self._inflight.append((ev, (d_images, d_keypoints, d_descriptors, d_counts)))
+            while self._inflight and self._inflight[0][0].query():
+                self._inflight.popleft()
+
+    def _torch_stream(self):
+        if self._ext_stream is None:
+            import torch
+            h = C.c_void_p()
+            check(lib().orbx_get_stream(self._ctx, C.byref(h)), "orbx_get_stream")
+            self._ext_stream = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", self.device))
+        return self._ext_stream
 
     def synchronize(self):
         check(lib().orbx_synchronize(self._ctx), "orbx_synchronize")
+        self._inflight.clear()
 
     STAGES = ("pyramid", "fast_cells", "octree", "orient_desc")
 

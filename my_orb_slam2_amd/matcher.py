@@ -1,5 +1,6 @@
 """Host mirror of the Hamming half of ORB_SLAM2::ORBmatcher (my_orb_slam2/include/ORBmatcher.h)
 and of the descriptor band search of Frame::ComputeStereoMatches (src/Frame.cc:503-586)."""
+import collections
 import ctypes as C
 
 import numpy as np
@@ -33,10 +34,17 @@ class HammingMatcher:
     def __init__(self, device=0):
         self._m = C.c_void_p()
         check(lib().orbx_matcher_create(int(device), C.byref(self._m)), "orbx_matcher_create")
+        self._device = int(device)
+        self._ext_stream = None
+        self._inflight = collections.deque()
         self.device = int(device)
 
     def close(self):
         if getattr(self, "_m", None) and self._m.value:
+            if self._inflight:
+                lib().orbx_matcher_synchronize(self._m)
+                self._inflight.clear()
+            self._ext_stream = None
             lib().orbx_matcher_destroy(self._m)
             self._m = C.c_void_p()
 
@@ -66,6 +74,7 @@ class HammingMatcher:
                                              int(index_base), C.c_void_p(d_idx.data_ptr()),
                                              C.c_void_p(d_d1.data_ptr()), C.c_void_p(d_d2.data_ptr()), sp),
               "orbx_hamming_knn2_device")
+        self._hold(stream, d_query, d_db, d_idx, d_d1, d_d2)
 
     def merge_device(self, d_idx, d_d1, d_d2, o_idx, o_d1, o_d2, init=256, stream=None):
         """Merge (nparts, nq) partial results of consecutive database shards."""
@@ -75,6 +84,7 @@ class HammingMatcher:
                                            C.c_void_p(d_d1.data_ptr()), C.c_void_p(d_d2.data_ptr()), int(init),
                                            C.c_void_p(o_idx.data_ptr()), C.c_void_p(o_d1.data_ptr()),
                                            C.c_void_p(o_d2.data_ptr()), sp), "orbx_knn2_merge_device")
+        self._hold(stream, d_idx, d_d1, d_d2, o_idx, o_d1, o_d2)
 
     def ratio_test_device(self, d_d1, d_d2, d_accept, th=TH_LOW, inclusive=True, ratio=0.6, stream=None):
         sp = C.c_void_p(stream) if stream else None
@@ -82,6 +92,7 @@ class HammingMatcher:
                                            C.c_void_p(d_d2.data_ptr()), int(th), 1 if inclusive else 0,
                                            float(ratio), C.c_void_p(d_accept.data_ptr()), sp),
               "orbx_ratio_test_device")
+        self._hold(stream, d_d1, d_d2, d_accept)
 
     def stereo_band_match_device(self, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, scale_factors, bf, b,
                                  d_best_idx, d_best_dist, stream=None):
@@ -95,6 +106,7 @@ class HammingMatcher:
             C.c_void_p(d_nr.data_ptr()), np_ptr(sf), sf.shape[0], float(bf), float(b),
             C.c_void_p(d_best_idx.data_ptr()), C.c_void_p(d_best_dist.data_ptr()), sp),
             "orbx_stereo_band_match_device")
+        self._hold(stream, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, d_best_idx, d_best_dist)
 
     def compute_stereo_matches_device(self, left, right, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, bf, b,
                                       d_uright, d_depth, stream=None):
@@ -107,6 +119,7 @@ class HammingMatcher:
             C.c_void_p(d_nl.data_ptr()), C.c_void_p(d_kr.data_ptr()), C.c_void_p(d_dr.data_ptr()),
             C.c_void_p(d_nr.data_ptr()), float(bf), float(b), C.c_void_p(d_uright.data_ptr()),
             C.c_void_p(d_depth.data_ptr()), sp), "orbx_compute_stereo_matches_device")
+        self._hold(stream, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, d_uright, d_depth)
 
     def search_for_initialization(self, keys1_un, desc1, keys2_un, desc2, cell_start2, cell_items2, bounds,
                                   prev_matched, window_size=100, nnratio=0.9, check_orientation=True):
@@ -176,6 +189,24 @@ class HammingMatcher:
             float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), C.c_void_p(d_kps_un.data_ptr()),
             C.c_void_p(d_cell_start.data_ptr()), C.c_void_p(d_cell_items.data_ptr()), sp),
             "orbx_undistort_assign_grid_device")
+        self._hold(stream, d_kps, d_counts, d_kps_un, d_cell_start, d_cell_items)
 
     def synchronize(self):
         check(lib().orbx_matcher_synchronize(self._m), "orbx_matcher_synchronize")
+        self._inflight.clear()
+
+    def _hold(self, stream, *tensors):
+        """The device calls return before their kernels run, on a stream torch's allocator does not know.
+        Keeps the tensors referenced until an event recorded behind the call has completed."""
+        if stream:
+            return
+        import torch
+        if self._ext_stream is None:
+            h = C.c_void_p()
+            check(lib().orbx_matcher_get_stream(self._m, C.byref(h)), "orbx_matcher_get_stream")
+            self._ext_stream = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", self._device))
+        ev = torch.cuda.Event()
+        ev.record(self._ext_stream)
+        self._inflight.append((ev, tensors))
+        while self._inflight and self._inflight[0][0].query():
+            self._inflight.popleft()
