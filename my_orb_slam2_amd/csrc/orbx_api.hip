@@ -551,6 +551,10 @@ struct orbx_matcher {
     void* scratch = nullptr;
     size_t scratchBytes = 0;
     float* scale = nullptr;   // device copy of scale factors [0..15] and inverse scale factors [16..31]
+    float hostScale[2 * ORBX_MAX_LEVELS] = {0};   // what `scale` holds
+    bool scaleValid = false;
+    hipEvent_t evIn[2] = {nullptr, nullptr};      // "the extractor contexts' work is done"
+    hipEvent_t evOut = nullptr;                   // "the matcher has read the contexts' pyramids"
 };
 
 namespace {
@@ -576,6 +580,8 @@ extern "C" int orbx_matcher_create(int device, orbx_matcher** out) {
     m->device = device;
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->scale), sizeof(float) * 2 * ORBX_MAX_LEVELS);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&m->evIn[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->evOut, hipEventDisableTiming);
     if (e != hipSuccess) {
         set_error("orbx_matcher_create: %s", hipGetErrorString(e));
         orbx_matcher_destroy(m);
@@ -590,6 +596,8 @@ extern "C" void orbx_matcher_destroy(orbx_matcher* m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->scratch) (void)hipFree(m->scratch);
     if (m->scale) (void)hipFree(m->scale);
+    for (hipEvent_t ev : {m->evIn[0], m->evIn[1], m->evOut})
+        if (ev) (void)hipEventDestroy(ev);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -702,6 +710,7 @@ extern "C" int orbx_stereo_band_match_device(orbx_matcher* m, int npairs, int ca
     if (npairs == 0) return ORBX_OK;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+    m->scaleValid = false;   // orbx_compute_stereo_matches_device re-uploads its own table
     HIP_TRY(hipMemcpyAsync(m->scale, scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, s));
     const float maxD = bf / b;   // mbf / minZ with minZ = mb (src/Frame.cc:533-535)
     HIP_TRY(launch_stereo_band(npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, m->scale, nlevels, maxD,
@@ -750,8 +759,14 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* lef
     }
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
-    if (left->lastStream != s) HIP_TRY(hipStreamSynchronize(left->lastStream));
-    if (right->lastStream != s) HIP_TRY(hipStreamSynchronize(right->lastStream));
+    // Order the streams on the device, without stopping the host: this call's kernels start after the two
+    // extractions, and whatever the contexts are given next starts after these kernels have read their pyramids.
+    orbx_ctx* side[2] = {left, right};
+    for (int i = 0; i < 2; i++)
+        if (side[i]->lastStream && side[i]->lastStream != s) {
+            HIP_TRY(hipEventRecord(m->evIn[i], side[i]->lastStream));
+            HIP_TRY(hipStreamWaitEvent(s, m->evIn[i], 0));
+        }
     const size_t n = (size_t)npairs * cap;
     int rc = matcher_scratch(m, n * 3 * sizeof(int32_t), s);
     if (rc) return rc;
@@ -764,8 +779,13 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* lef
         host[l] = left->tab.scale[l];
         host[ORBX_MAX_LEVELS + l] = left->tab.invScale[l];
     }
-    HIP_TRY(hipMemcpyAsync(m->scale, host, sizeof(host), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));   // `host` is a stack buffer
+    if (!m->scaleValid || memcmp(host, m->hostScale, sizeof(host)) != 0) {   // first call, or other extractor settings
+        HIP_TRY(hipStreamSynchronize(s));                                    // earlier kernels may still read m->scale
+        memcpy(m->hostScale, host, sizeof(host));
+        HIP_TRY(hipMemcpyAsync(m->scale, m->hostScale, sizeof(host), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        m->scaleValid = true;
+    }
     const float maxD = bf / b;          // mbf / minZ with minZ = mb (src/Frame.cc:533-535)
     HIP_TRY(launch_stereo_band(npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, m->scale, nl, maxD, bestIdx,
                                bestDist, s));
@@ -774,6 +794,12 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* lef
     pyramid_view(right, rv);
     HIP_TRY(launch_stereo_refine(npairs, cap, lv, rv, d_kl, d_nl, d_kr, bestIdx, bestDist, m->scale,
                                  m->scale + ORBX_MAX_LEVELS, bf, maxD, d_uright, d_depth, sad, s));
+    HIP_TRY(hipEventRecord(m->evOut, s));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipStreamWaitEvent(side[i]->stream, m->evOut, 0));
+        if (side[i]->lastStream && side[i]->lastStream != side[i]->stream && side[i]->lastStream != s)
+            HIP_TRY(hipStreamWaitEvent(side[i]->lastStream, m->evOut, 0));
+    }
     return ORBX_OK;
 }
 

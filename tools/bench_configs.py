@@ -77,12 +77,11 @@ def main():
         def step(i):
             exl.extract_batch_device(left, kl, dl, nl)
             exr.extract_batch_device(right, kr, dr, nr)
-            exl.synchronize()      # the matcher's stream reads both contexts' outputs and pyramids
-            exr.synchronize()
+            # no host synchronisation: the call orders the three streams on the device (events)
             hm.compute_stereo_matches_device(exl, exr, kl, dl, nl, kr, dr, nr, bf, b, ur, z)
-            hm.synchronize()
         steps = 16
         dt = timed(torch, dist, world, step, steps, 2)
+        hm.synchronize()
         if rank == 0:
             matched = float((ur >= 0).sum().item()) / B
             print(json.dumps({"workload": "configs[2] stereo pairs, 752x480, nFeatures 1200, extraction x2 + ComputeStereoMatches",
