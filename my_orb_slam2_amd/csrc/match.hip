@@ -14,6 +14,8 @@
 // No MFMA: this is integer bit-counting, not a dense float contraction.
 #include "orbx_internal.h"
 
+#include <cmath>
+
 namespace orbx {
 
 namespace {
@@ -150,41 +152,151 @@ __global__ __launch_bounds__(256) void ratio_test_kernel(int64_t nq, const int32
     accept[qi] = ok ? 1 : 0;
 }
 
-// One thread per left keypoint walks every right keypoint of its pair in index order; the row
-// table of the reference (:513-530) becomes the test minr <= (int)vL <= maxr on each right point.
+// Band search of Frame::ComputeStereoMatches (src/Frame.cc:513-586). The reference files every right
+// keypoint under all image rows of its band (:520-530) and lets a left keypoint scan the list of its row.
+// Here both sides of a pair are first counting-sorted by row in LDS (right keypoints by the first row of
+// their band, left keypoints by their own row). A wave then holds 64 left keypoints of neighbouring rows
+// and only walks the right keypoints whose band can reach those rows, a contiguous stretch of the sorted
+// list found from the sort's row-start table. Right keypoints arrive through scalar loads; the 256-bit
+// distance is computed only when some lane passes the row / octave / column tests. The best match is kept as
+// the key (distance << 16 | right index), so the lowest index wins ties whatever the visiting order (:580
+// is a strict `<` over ascending indices).
+constexpr int kRowBins = 4096 + 64;     // images are at most 4096 rows; keys are clamped into [0, kRowBins)
+
+struct StereoSorted {        // per pair, in the matcher's scratch
+    int32_t* rStart;         // [kRowBins + 1] first sorted right keypoint whose band starts at row >= r
+    uint32_t* rBand;         // [cap] (minr & 0xffff) | maxr << 16, sorted by max(minr, 0)
+    float* rX;               // [cap] column
+    uint32_t* rOctIdx;       // [cap] octave << 16 | index in the caller's array
+    int32_t* lPerm;          // [cap] left keypoint indices sorted by row
+};
+
+__device__ __forceinline__ StereoSorted sorted_of_pair(uint8_t* work, int cap, int pair) {
+    const size_t per = sizeof(int32_t) * ((size_t)kRowBins + 1 + 4 * (size_t)cap);
+    uint8_t* p = work + per * pair;
+    StereoSorted v;
+    v.rStart = reinterpret_cast<int32_t*>(p);
+    v.rBand = reinterpret_cast<uint32_t*>(v.rStart + kRowBins + 1);
+    v.rX = reinterpret_cast<float*>(v.rBand + cap);
+    v.rOctIdx = reinterpret_cast<uint32_t*>(v.rX + cap);
+    v.lPerm = reinterpret_cast<int32_t*>(v.rOctIdx + cap);
+    return v;
+}
+
+// Exclusive scan of hist[0 .. kRowBins] (kRowBins + 1 entries, the last one receives the total). 256 threads.
+__device__ void scan_rows(int* hist, int* part) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    constexpr int per = (kRowBins + 255) / 256;
+    const int b = min(t * per, kRowBins), e = min(b + per, kRowBins);
+    int s = 0;
+    for (int i = b; i < e; i++) s += hist[i];
+    int incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) part[wv] = incl;
+    __syncthreads();
+    int run = incl - s;
+    for (int w = 0; w < wv; w++) run += part[w];
+    for (int i = b; i < e; i++) {
+        const int c = hist[i];
+        hist[i] = run;
+        run += c;
+    }
+    if (t == 255) hist[kRowBins] = run;
+    __syncthreads();
+}
+
+// One workgroup per pair: counting sort of both sides by row.
+__global__ __launch_bounds__(256) void stereo_sort_kernel(int cap, const orbx_keypoint* __restrict__ kl,
+                                                          const int32_t* __restrict__ nl,
+                                                          const orbx_keypoint* __restrict__ kr,
+                                                          const int32_t* __restrict__ nr,
+                                                          const float* __restrict__ scale, int nlevels,
+                                                          uint8_t* __restrict__ work) {
+    __shared__ int hist[kRowBins + 1];
+    __shared__ int part[4];
+    const int pair = blockIdx.x, t = threadIdx.x;
+    const int nL = min(nl[pair], cap), nR = min(nr[pair], cap);
+    const long long o = (long long)pair * cap;
+    const StereoSorted S = sorted_of_pair(work, cap, pair);
+    // ---- right side: key = first row of the band (:524-526) ----
+    for (int i = t; i <= kRowBins; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int i = t; i < nR; i += 256) {
+        const orbx_keypoint R = kr[o + i];
+        const float r = __fmul_rn(2.0f, scale[min(max(R.octave, 0), nlevels - 1)]);
+        const int minr = (int)floorf(__fsub_rn(R.y, r));
+        atomicAdd(&hist[min(max(minr, 0), kRowBins - 1)], 1);
+    }
+    __syncthreads();
+    scan_rows(hist, part);
+    for (int i = t; i <= kRowBins; i += 256) S.rStart[i] = hist[i];
+    __syncthreads();
+    for (int i = t; i < nR; i += 256) {
+        const orbx_keypoint R = kr[o + i];
+        const float r = __fmul_rn(2.0f, scale[min(max(R.octave, 0), nlevels - 1)]);
+        const int maxr = (int)ceilf(__fadd_rn(R.y, r)), minr = (int)floorf(__fsub_rn(R.y, r));
+        const int pos = atomicAdd(&hist[min(max(minr, 0), kRowBins - 1)], 1);   // order inside a row is free
+        S.rBand[pos] = ((uint32_t)minr & 0xffffu) | ((uint32_t)maxr << 16);
+        S.rX[pos] = R.x;
+        S.rOctIdx[pos] = ((uint32_t)R.octave << 16) | (uint32_t)i;
+    }
+    __syncthreads();
+    // ---- left side: key = the row the keypoint looks up, (int)vL (:548) ----
+    for (int i = t; i <= kRowBins; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int i = t; i < nL; i += 256) atomicAdd(&hist[min(max((int)kl[o + i].y, 0), kRowBins - 1)], 1);
+    __syncthreads();
+    scan_rows(hist, part);
+    for (int i = t; i < nL; i += 256) S.lPerm[atomicAdd(&hist[min(max((int)kl[o + i].y, 0), kRowBins - 1)], 1)] = i;
+}
+
 __global__ __launch_bounds__(256) void stereo_band_kernel(int cap, const orbx_keypoint* __restrict__ kl,
                                                           const uint4* __restrict__ dl, const int32_t* __restrict__ nl,
-                                                          const orbx_keypoint* __restrict__ kr,
-                                                          const uint4* __restrict__ dr, const int32_t* __restrict__ nr,
-                                                          const float* __restrict__ scale, int nlevels, float maxD,
-                                                          int32_t* __restrict__ bestIdx, int32_t* __restrict__ bestDist) {
+                                                          const uint4* __restrict__ dr, float maxD, int bandRows,
+                                                          uint8_t* __restrict__ work, int32_t* __restrict__ bestIdx,
+                                                          int32_t* __restrict__ bestDist) {
     const int pair = blockIdx.y;
-    const int iL = blockIdx.x * 256 + threadIdx.x;
-    const int nL = min(nl[pair], cap), nR = min(nr[pair], cap);
-    if (iL >= nL) return;
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    const int nL = min(nl[pair], cap);
+    if ((pos & ~63) >= nL) return;                  // whole wave past the end (also nL == 0)
     const long long o = (long long)pair * cap;
+    const StereoSorted S = sorted_of_pair(work, cap, pair);
+    const bool live = pos < nL;
+    const int iL = S.lPerm[live ? pos : nL - 1];    // idle lanes shadow the last keypoint
     const orbx_keypoint L = kl[o + iL];
     const uint4 qa = dl[2 * (o + iL)], qb = dl[2 * (o + iL) + 1];
     const int row = (int)L.y;                       // vRowIndices[vL], float -> index truncation (:548)
     const float minU = __fsub_rn(L.x, maxD), maxU = L.x;   // minD = 0 (:534,553-554)
-    int best = 100, bi = -1;                        // TH_HIGH (:559)
-    if (maxU >= 0) {                                // (:556)
-        for (int iR = 0; iR < nR; iR++) {
-            const orbx_keypoint R = kr[o + iR];     // wave-uniform address
-            const int oct = min(max(R.octave, 0), nlevels - 1);
-            const float r = __fmul_rn(2.0f, scale[oct]);
-            const int maxr = (int)ceilf(__fadd_rn(R.y, r)), minr = (int)floorf(__fsub_rn(R.y, r));
-            if (row < minr || row > maxr) continue;
-            if (R.octave < L.octave - 1 || R.octave > L.octave + 1) continue;   // (:570)
-            if (!(R.x >= minU && R.x <= maxU)) continue;                        // (:575)
-            const uint4 ra = dr[2 * (o + iR)], rb = dr[2 * (o + iR) + 1];
-            const int d = __popc(qa.x ^ ra.x) + __popc(qa.y ^ ra.y) + __popc(qa.z ^ ra.z) + __popc(qa.w ^ ra.w) +
-                          __popc(qb.x ^ rb.x) + __popc(qb.y ^ rb.y) + __popc(qb.z ^ rb.z) + __popc(qb.w ^ rb.w);
-            if (d < best) { best = d; bi = iR; }    // strict: lowest right index wins ties (:580)
-        }
+    // the wave's rows are ascending; a band spans at most bandRows rows
+    const int rowLo = __builtin_amdgcn_readfirstlane(row), rowHi = __builtin_amdgcn_readlane(row, 63);
+    const int jBeg = S.rStart[min(max(rowLo - bandRows, 0), kRowBins)];
+    const int jEnd = S.rStart[min(max(rowHi + 1, 0), kRowBins)];
+    unsigned best = 100u << 16;                     // TH_HIGH (:559), no index
+    for (int j = jBeg; j < jEnd; j++) {
+        const uint32_t band = S.rBand[j];           // wave-uniform addresses: scalar loads
+        const uint32_t oi = S.rOctIdx[j];
+        const float rx = S.rX[j];
+        const int minr = (int)(short)(band & 0xffffu), maxr = (int)(short)(band >> 16);
+        const int roct = (int)(short)(oi >> 16);
+        const bool pass = maxU >= 0 && row >= minr && row <= maxr &&               // (:556, :548)
+                          roct >= L.octave - 1 && roct <= L.octave + 1 &&          // (:570)
+                          rx >= minU && rx <= maxU;                                // (:575)
+        if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
+        const uint32_t iR = oi & 0xffffu;
+        const uint4 ra = dr[2 * (o + iR)], rb = dr[2 * (o + iR) + 1];
+        const int d = __popc(qa.x ^ ra.x) + __popc(qa.y ^ ra.y) + __popc(qa.z ^ ra.z) + __popc(qa.w ^ ra.w) +
+                      __popc(qb.x ^ rb.x) + __popc(qb.y ^ rb.y) + __popc(qb.z ^ rb.z) + __popc(qb.w ^ rb.w);
+        if (pass) best = min(best, ((unsigned)d << 16) | iR);   // d < 100 or nothing; lowest index wins ties (:580)
     }
-    bestIdx[o + iL] = bi;
-    bestDist[o + iL] = best;
+    if (live) {
+        const int d = (int)(best >> 16);
+        bestIdx[o + iL] = d < 100 ? (int)(best & 0xffffu) : -1;
+        bestDist[o + iL] = d;
+    }
 }
 
 // Second half of Frame::ComputeStereoMatches (src/Frame.cc:589-661): for every left keypoint whose
@@ -386,14 +498,26 @@ hipError_t launch_ratio_test(int64_t nq, const int32_t* d1, const int32_t* d2, i
     return hipGetLastError();
 }
 
+size_t stereo_band_scratch_bytes(int npairs, int cap) {
+    return sizeof(int32_t) * ((size_t)kRowBins + 1 + 4 * (size_t)cap) * (size_t)npairs;
+}
+
+// maxScale: the largest scale factor (a band is 2 * scale rows either side of the keypoint).
 hipError_t launch_stereo_band(int npairs, int cap, const orbx_keypoint* kl, const uint8_t* dl,
                               const int32_t* nl, const orbx_keypoint* kr, const uint8_t* dr,
-                              const int32_t* nr, const float* scale, int nlevels, float maxD,
-                              int32_t* bestIdx, int32_t* bestDist, hipStream_t s) {
+                              const int32_t* nr, const float* scale, int nlevels, float maxScale, float maxD,
+                              void* work, int32_t* bestIdx, int32_t* bestDist, hipStream_t s) {
     if (npairs <= 0 || cap <= 0) return hipSuccess;
+    if (cap > 65535) return hipErrorInvalidValue;                 // the right index shares a key with the distance
+    hipLaunchKernelGGL(stereo_sort_kernel, dim3(npairs), dim3(256), 0, s, cap, kl, nl, kr, nr, scale, nlevels,
+                       static_cast<uint8_t*>(work));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int bandRows = 2 * (int)std::ceil(2.0f * maxScale) + 2;   // maxr - minr never exceeds this
     dim3 grid((cap + 255) / 256, npairs, 1), block(256, 1, 1);
     hipLaunchKernelGGL(stereo_band_kernel, grid, block, 0, s, cap, kl, reinterpret_cast<const uint4*>(dl), nl,
-                       kr, reinterpret_cast<const uint4*>(dr), nr, scale, nlevels, maxD, bestIdx, bestDist);
+                       reinterpret_cast<const uint4*>(dr), maxD, bandRows, static_cast<uint8_t*>(work), bestIdx,
+                       bestDist);
     return hipGetLastError();
 }
 

@@ -713,8 +713,12 @@ extern "C" int orbx_stereo_band_match_device(orbx_matcher* m, int npairs, int ca
     m->scaleValid = false;   // orbx_compute_stereo_matches_device re-uploads its own table
     HIP_TRY(hipMemcpyAsync(m->scale, scale_factors, sizeof(float) * nlevels, hipMemcpyHostToDevice, s));
     const float maxD = bf / b;   // mbf / minZ with minZ = mb (src/Frame.cc:533-535)
-    HIP_TRY(launch_stereo_band(npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, m->scale, nlevels, maxD,
-                               d_best_idx, d_best_dist, s));
+    int rc = matcher_scratch(m, stereo_band_scratch_bytes(npairs, cap), s);
+    if (rc) return rc;
+    float maxScale = 0.f;
+    for (int l = 0; l < nlevels; l++) maxScale = std::max(maxScale, scale_factors[l]);
+    HIP_TRY(launch_stereo_band(npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, m->scale, nlevels, maxScale, maxD,
+                               m->scratch, d_best_idx, d_best_dist, s));
     return ORBX_OK;
 }
 
@@ -768,9 +772,10 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* lef
             HIP_TRY(hipStreamWaitEvent(s, m->evIn[i], 0));
         }
     const size_t n = (size_t)npairs * cap;
-    int rc = matcher_scratch(m, n * 3 * sizeof(int32_t), s);
+    const size_t bandBytes = (stereo_band_scratch_bytes(npairs, cap) + 255) / 256 * 256;
+    int rc = matcher_scratch(m, bandBytes + n * 3 * sizeof(int32_t), s);
     if (rc) return rc;
-    int32_t* bestIdx = static_cast<int32_t*>(m->scratch);
+    int32_t* bestIdx = reinterpret_cast<int32_t*>(static_cast<uint8_t*>(m->scratch) + bandBytes);
     int32_t* bestDist = bestIdx + n;
     int32_t* sad = bestDist + n;
     const int nl = left->cfg.nlevels;
@@ -787,8 +792,10 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* lef
         m->scaleValid = true;
     }
     const float maxD = bf / b;          // mbf / minZ with minZ = mb (src/Frame.cc:533-535)
-    HIP_TRY(launch_stereo_band(npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, m->scale, nl, maxD, bestIdx,
-                               bestDist, s));
+    float maxScale = 0.f;
+    for (int l = 0; l < nl; l++) maxScale = std::max(maxScale, host[l]);
+    HIP_TRY(launch_stereo_band(npairs, cap, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, m->scale, nl, maxScale, maxD,
+                               m->scratch, bestIdx, bestDist, s));
     PyramidView lv, rv;
     pyramid_view(left, lv);
     pyramid_view(right, rv);

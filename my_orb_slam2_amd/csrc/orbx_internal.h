@@ -140,10 +140,11 @@ hipError_t launch_knn2_merge(int nparts, int64_t nq, const int64_t* idx, const i
                              hipStream_t s);
 hipError_t launch_ratio_test(int64_t nq, const int32_t* d1, const int32_t* d2, int32_t th, int inclusive,
                              float ratio, uint8_t* accept, hipStream_t s);
+size_t stereo_band_scratch_bytes(int npairs, int cap);
 hipError_t launch_stereo_band(int npairs, int cap, const orbx_keypoint* kl, const uint8_t* dl,
                               const int32_t* nl, const orbx_keypoint* kr, const uint8_t* dr,
-                              const int32_t* nr, const float* scale, int nlevels, float maxD,
-                              int32_t* bestIdx, int32_t* bestDist, hipStream_t s);
+                              const int32_t* nr, const float* scale, int nlevels, float maxScale, float maxD,
+                              void* work, int32_t* bestIdx, int32_t* bestDist, hipStream_t s);
 
 hipError_t launch_stereo_refine(int npairs, int cap, const PyramidView& left, const PyramidView& right,
                                 const orbx_keypoint* kl, const int32_t* nl, const orbx_keypoint* kr,
