@@ -135,8 +135,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    # ORBX_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (rehearsal on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     B = a.batch
     unique = max(B, (a.unique + B - 1) // B * B)
 
@@ -161,7 +165,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +177,7 @@ def main():
         step(i)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -190,7 +194,7 @@ def main():
     ex.set_profiling(False)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
     fps = world * B * a.steps / dt
@@ -232,7 +236,7 @@ def main():
         h = hamming_bench(torch, local)
         out["hamming"] = {k: (round(v, 4) if isinstance(v, float) and v < 1e6 else v) for k, v in h.items()}
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
