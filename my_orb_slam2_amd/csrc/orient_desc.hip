@@ -155,16 +155,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k;
     const float p5 = 0.1555786518463281f * k, p7 = -0.04432655554792128f * k;
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, __fadd_rn(ax, (float)2.2204460492503131e-16));
-        c2 = __fmul_rn(c, c);
-        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-    } else {
-        c = __fdiv_rn(ax, __fadd_rn(ay, (float)2.2204460492503131e-16));
-        c2 = __fmul_rn(c, c);
-        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-    }
+    // both branches of the original divide the smaller magnitude by (the larger + DBL_EPSILON) and run the same
+    // polynomial; only the last step differs, so the quotient and the polynomial are evaluated once
+    const float c = __fdiv_rn(fminf(ax, ay), __fadd_rn(fmaxf(ax, ay), (float)2.2204460492503131e-16));
+    const float c2 = __fmul_rn(c, c);
+    const float p = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    float a = ax >= ay ? p : __fsub_rn(90.f, p);
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);
     return a;
@@ -212,6 +208,15 @@ __device__ __forceinline__ int wave_sum(int x) {
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// min(255, v >> 16) of four 16.16 sums (each below 2^31) as four bytes: the high halves of two sums are paired
+// by v_perm_b32 and v_sat_pk_u8_i16 saturates and packs a pair.
+__device__ __forceinline__ uint32_t pack4_sat(const uint4& v) {
+    uint32_t lo, hi;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(lo) : "v"(__builtin_amdgcn_perm(v.y, v.x, 0x07060302u)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(hi) : "v"(__builtin_amdgcn_perm(v.w, v.z, 0x07060302u)));
+    return (lo & 0xffffu) | (hi << 16);
 }
 
 __device__ __forceinline__ uint32_t row_sum4(uint32_t x, uint32_t klo, uint32_t khi, uint32_t y) {
@@ -384,10 +389,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
                 o.w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.w), b, o.w, false);
             }
             uint32_t* bl = reinterpret_cast<uint32_t*>(R + (vItem[q] >> 16));
-            bl[0] = min(e.x >> 16, 255u) | (min(e.y >> 16, 255u) << 8) | (min(e.z >> 16, 255u) << 16) |
-                    (min(e.w >> 16, 255u) << 24);
-            bl[kTPitch / 4] = min(o.x >> 16, 255u) | (min(o.y >> 16, 255u) << 8) | (min(o.z >> 16, 255u) << 16) |
-                              (min(o.w >> 16, 255u) << 24);
+            bl[0] = pack4_sat(e);
+            bl[kTPitch / 4] = pack4_sat(o);
         }
     }
     wave_sync();
