@@ -87,8 +87,10 @@ int orbx_get_scale_sigma_squares(const orbx_ctx* ctx, float* out);
 int orbx_get_inverse_scale_sigma_squares(const orbx_ctx* ctx, float* out);
 int orbx_get_features_per_level(const orbx_ctx* ctx, int32_t* out); /* mnFeaturesPerLevel (:427-438) */
 int orbx_get_umax(const orbx_ctx* ctx, int32_t* out16);              /* umax (:446-461) */
-/* Capacity that can never overflow: sum over levels of (quota + 3); each level yields at most
- * quota + 3 keypoints (src/ORBextractor.cc:661-723). */
+/* Capacity for images of the context's maximum size: sum over levels of max(quota + 3, 4 * nIni). A level
+ * yields at most quota + 3 keypoints once the node list nears the quota (src/ORBextractor.cc:661-723), but the
+ * first sweep splits all nIni = round(width / height) root nodes whatever the quota (:598-657). A smaller
+ * image with a more extreme aspect ratio can need more; the extract calls report ORBX_ERR_CAPACITY then. */
 int orbx_keypoint_capacity(const orbx_ctx* ctx);
 
 /* ORBextractor::operator() (src/ORBextractor.cc:1035-1097) on one host image (CV_8UC1 rows of

@@ -248,9 +248,9 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
     __syncthreads();
     for (int i = t; i < Lc; i += kThreads) {
         const unsigned p = 0xFFFFFFu - ((unsigned)best[i] & 0xFFFFFFu);
-        if (i < N + kSelPad) selOut[i] = cand[p];
+        if (i < L.selCap) selOut[i] = cand[p];
     }
-    if (t == 0) *selCountOut = min(Lc, N + kSelPad);
+    if (t == 0) *selCountOut = min(Lc, L.selCap);
 }
 
 }  // namespace

@@ -233,8 +233,9 @@ extern "C" int orbx_get_umax(const orbx_ctx* c, int32_t* out16) {
 }
 extern "C" int orbx_keypoint_capacity(const orbx_ctx* c) {
     if (!c) return 0;
+    // per level max(quota + 3, 4 * nIni), nIni taken from the context's largest image
     int cap = 0;
-    for (int q : c->tab.perLevel) cap += q + 3;
+    for (int l = 0; l < c->maxGeom.nlevels; l++) cap += std::max(c->tab.perLevel[l] + 3, 4 * c->maxGeom.lv[l].nIni);
     return cap;
 }
 

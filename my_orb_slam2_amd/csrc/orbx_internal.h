@@ -16,7 +16,7 @@ constexpr int kBorder = 16;      // EDGE_THRESHOLD - 3: first column/row FAST ma
 constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE (:65)
 constexpr int kPatchSize = 31;   // PATCH_SIZE (:64)
 constexpr float kCellSize = 30;  // W (:761)
-constexpr int kSelPad = 4;       // a level keeps at most quota+3 nodes; slots are quota+kSelPad
+constexpr int kSelPad = 4;       // a level keeps at most max(quota + 3, 4 * nIni) nodes; see LevelGeom::selCap
 
 // Geometry of one pyramid level for the current image size. Passed to kernels by value.
 struct LevelGeom {
@@ -29,7 +29,9 @@ struct LevelGeom {
     int slotCap;            // candidate capacity of one cell
     long long slotBase;     // first slot entry of this level in a frame's slot / candidate arrays
     int quota;              // mnFeaturesPerLevel[level]
-    int selBase;            // first entry of this level's selected-keypoint region (quota+kSelPad long)
+    int selBase;            // first entry of this level's selected-keypoint region (selCap long)
+    int selCap;             // most keypoints the quadtree can keep: the first sweep splits all nIni root nodes
+                            // whatever the quota (up to 4 * nIni nodes), later splits stop within 3 of the quota
     int nIni;               // root nodes of the quadtree (:535)
     float hX;               // root width (:537)
     float scale;            // mvScaleFactor[level]

@@ -116,7 +116,8 @@ bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g,
         L.selBase = sel;
         cells += nCols * nRows;
         slots += (long long)nCols * nRows * L.slotCap;
-        sel += L.quota + kSelPad;
+        L.selCap = std::max(L.quota + kSelPad, 4 * nIni + 1);
+        sel += L.selCap;
         g.nodeCap = std::max(g.nodeCap, std::max(L.quota + 8, 4 * nIni + 8));
         if (nCols) {
             maxWCell = std::max(maxWCell, L.wCell);

@@ -115,6 +115,17 @@ def test_other_parameters():
     compare_frame(gpu, cpu, m.synth_frame(4))
 
 
+@pytest.mark.parametrize("kw", [dict(nfeatures=50), dict(nfeatures=5000, w=1241, h=376), dict(nfeatures=2000, scale=2.0, nlevels=4),
+                                dict(nfeatures=800, scale=1.1, nlevels=12), dict(nfeatures=1000, ini=7, mn=7),
+                                dict(nfeatures=1000, ini=60, mn=40), dict(nfeatures=1000, nlevels=8, scale=1.2, ini=20, mn=5)])
+def test_parameter_corners(kw):
+    """Quotas from a handful to more corners than the image has, the smallest and largest pyramid steps, equal
+    and very high thresholds (many cells fall back, or stay empty)."""
+    gpu, cpu = make(**kw)
+    n = compare_frame(gpu, cpu, m.synth_frame(17, kw.get("w", 752), kw.get("h", 480)))
+    assert n > 0
+
+
 def test_unaligned_rows_and_smaller_image_in_big_context():
     gpu, cpu = make(w=800, h=600)
     big = np.zeros((480, 757), np.uint8)
