@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
     uint32_t* selOut = fs.sel + (long long)f * g.totalSel + L.selBase;
     int32_t* selCountOut = fs.selCount + (long long)f * g.nlevels + l;
     const int nCells = L.nCols * L.nRows;
-    if (nCells == 0 || L.quota <= 0) {
+    if (nCells == 0) {   // (a quota of 0 still keeps the children of the first sweep, as in the reference)
         if (t == 0) *selCountOut = 0;
         return;
     }

@@ -123,7 +123,7 @@ class Extractor:
         self.h = lib().orc_create(nfeatures, scale, nlevels, ini, mn, blur)
         assert self.h
         self.nlevels = nlevels
-        self.cap = nfeatures + 4 * nlevels + 64
+        self.cap = nfeatures + 300 * nlevels + 64   # a level can keep 4 * round(width / height) keypoints whatever its quota
 
     def __del__(self):
         if getattr(self, "h", None):
