@@ -126,6 +126,16 @@ def test_parameter_corners(kw):
     assert n > 0
 
 
+def test_levels_with_quota_zero_or_one():
+    """nfeatures = 5 over 6 levels gives quotas 2 1 1 1 0 0; DistributeOctTree still splits the root node once
+    (src/ORBextractor.cc:598-657) and keeps its four children at every level, also where the quota is 0."""
+    from my_orb_slam2_amd import synth as S
+    gpu, cpu = make(nfeatures=5, w=823, h=610, nlevels=6, scale=1.33, ini=6, mn=2)
+    assert list(cpu.features_per_level()) == [2, 1, 1, 1, 0, 0]
+    n = compare_frame(gpu, cpu, m.synth_frame(1038, 823, 610, kind=S.NOISE))
+    assert n == 24
+
+
 def test_unaligned_rows_and_smaller_image_in_big_context():
     gpu, cpu = make(w=800, h=600)
     big = np.zeros((480, 757), np.uint8)
