@@ -121,7 +121,8 @@ class ORBextractor:
         return [(kps[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(b)]
 
     def extract_batch_device(self, d_images, d_keypoints, d_descriptors, d_counts, stream=None):
-        """Device batch on torch CUDA tensors (no copies, no synchronisation):
+        """Device batch on torch CUDA tensors (no copies, no host synchronisation; call synchronize() or order
+        your own stream against the context's before reading the outputs):
         d_images (B, H, W) uint8, d_keypoints (B, cap, 7) float32/int32 view (28-byte records),
         d_descriptors (B, cap, 32) uint8, d_counts (B,) int32."""
         b, h, w = d_images.shape
@@ -131,6 +132,11 @@ class ORBextractor:
         assert d_keypoints.shape[0] == b and d_keypoints.shape[1] == cap and d_keypoints.element_size() * \
             d_keypoints.shape[2] == 28 and d_keypoints.is_contiguous() and d_descriptors.is_contiguous()
         sp = C.c_void_p(stream) if stream else None
+        if not stream:
+            # the context's stream does not synchronise with torch's streams by itself: let it wait for whatever
+            # torch has queued so far on the current stream (the producers of d_images, fills of the outputs)
+            import torch
+            self._torch_stream().wait_event(torch.cuda.current_stream().record_event())
         check(lib().orbx_extract_batch_device(self._ctx, C.c_void_p(d_images.data_ptr()), b, w, h,
                                               d_images.stride(1), d_images.stride(0),
                                               C.c_void_p(d_keypoints.data_ptr()),

@@ -69,6 +69,7 @@ class HammingMatcher:
     def knn2_device(self, d_query, d_db, d_idx, d_d1, d_d2, init=256, index_base=0, stream=None):
         """torch CUDA tensors: (nq, 32) / (ndb, 32) uint8 in, int64 / int32 / int32 (nq,) out."""
         sp = C.c_void_p(stream) if stream else None
+        self._before(stream)
         check(lib().orbx_hamming_knn2_device(self._m, C.c_void_p(d_query.data_ptr()), d_query.shape[0],
                                              C.c_void_p(d_db.data_ptr()), d_db.shape[0], int(init),
                                              int(index_base), C.c_void_p(d_idx.data_ptr()),
@@ -80,6 +81,7 @@ class HammingMatcher:
         """Merge (nparts, nq) partial results of consecutive database shards."""
         nparts, nq = d_idx.shape
         sp = C.c_void_p(stream) if stream else None
+        self._before(stream)
         check(lib().orbx_knn2_merge_device(self._m, nparts, nq, C.c_void_p(d_idx.data_ptr()),
                                            C.c_void_p(d_d1.data_ptr()), C.c_void_p(d_d2.data_ptr()), int(init),
                                            C.c_void_p(o_idx.data_ptr()), C.c_void_p(o_d1.data_ptr()),
@@ -88,6 +90,7 @@ class HammingMatcher:
 
     def ratio_test_device(self, d_d1, d_d2, d_accept, th=TH_LOW, inclusive=True, ratio=0.6, stream=None):
         sp = C.c_void_p(stream) if stream else None
+        self._before(stream)
         check(lib().orbx_ratio_test_device(self._m, d_d1.shape[0], C.c_void_p(d_d1.data_ptr()),
                                            C.c_void_p(d_d2.data_ptr()), int(th), 1 if inclusive else 0,
                                            float(ratio), C.c_void_p(d_accept.data_ptr()), sp),
@@ -100,6 +103,7 @@ class HammingMatcher:
         npairs, cap = d_dl.shape[0], d_dl.shape[1]
         sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
         sp = C.c_void_p(stream) if stream else None
+        self._before(stream)
         check(lib().orbx_stereo_band_match_device(
             self._m, npairs, cap, C.c_void_p(d_kl.data_ptr()), C.c_void_p(d_dl.data_ptr()),
             C.c_void_p(d_nl.data_ptr()), C.c_void_p(d_kr.data_ptr()), C.c_void_p(d_dr.data_ptr()),
@@ -114,6 +118,7 @@ class HammingMatcher:
         (two ORBextractor objects) extracted in their last batched call. Fills mvuRight / mvDepth."""
         npairs, cap = d_dl.shape[0], d_dl.shape[1]
         sp = C.c_void_p(stream) if stream else None
+        self._before(stream)
         check(lib().orbx_compute_stereo_matches_device(
             self._m, left._ctx, right._ctx, npairs, cap, C.c_void_p(d_kl.data_ptr()), C.c_void_p(d_dl.data_ptr()),
             C.c_void_p(d_nl.data_ptr()), C.c_void_p(d_kr.data_ptr()), C.c_void_p(d_dr.data_ptr()),
@@ -184,6 +189,7 @@ class HammingMatcher:
         d_cell_start is (nframes, 64*48+1) int32, d_cell_items (nframes, cap) int32."""
         nframes, cap = d_kps.shape[0], d_kps.shape[1]
         sp = C.c_void_p(stream) if stream else None
+        self._before(stream)
         check(lib().orbx_undistort_assign_grid_device(
             self._m, nframes, cap, C.c_void_p(d_kps.data_ptr()), C.c_void_p(d_counts.data_ptr()), C.byref(cam),
             float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), C.c_void_p(d_kps_un.data_ptr()),
@@ -195,18 +201,30 @@ class HammingMatcher:
         check(lib().orbx_matcher_synchronize(self._m), "orbx_matcher_synchronize")
         self._inflight.clear()
 
+    def _own_stream(self):
+        import torch
+        if self._ext_stream is None:
+            h = C.c_void_p()
+            check(lib().orbx_matcher_get_stream(self._m, C.byref(h)), "orbx_matcher_get_stream")
+            self._ext_stream = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", self._device))
+        return self._ext_stream
+
+    def _before(self, stream):
+        """The matcher's stream does not synchronise with torch's streams by itself: let it wait for what torch
+        has queued so far on the current stream (producers of the inputs, fills of the outputs)."""
+        if stream:
+            return
+        import torch
+        self._own_stream().wait_event(torch.cuda.current_stream().record_event())
+
     def _hold(self, stream, *tensors):
         """The device calls return before their kernels run, on a stream torch's allocator does not know.
         Keeps the tensors referenced until an event recorded behind the call has completed."""
         if stream:
             return
         import torch
-        if self._ext_stream is None:
-            h = C.c_void_p()
-            check(lib().orbx_matcher_get_stream(self._m, C.byref(h)), "orbx_matcher_get_stream")
-            self._ext_stream = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", self._device))
         ev = torch.cuda.Event()
-        ev.record(self._ext_stream)
+        ev.record(self._own_stream())
         self._inflight.append((ev, tensors))
         while self._inflight and self._inflight[0][0].query():
             self._inflight.popleft()
