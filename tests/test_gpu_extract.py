@@ -217,6 +217,32 @@ def test_two_contexts_like_stereo():
     assert np.array_equal(kl["x"], ckl["x"]) and np.array_equal(kr["y"], ckr["y"])
 
 
+def test_two_host_threads_like_the_reference_stereo_frame():
+    """Frame's stereo constructor runs the left and right extractor on two threads at once
+    (src/Frame.cc:97-110): two contexts driven concurrently from two host threads, many frames each."""
+    import threading
+    nframes = 24
+    errors = []
+
+    def work(right_view):
+        try:
+            gpu, cpu = make(nfeatures=1200)
+            for i in range(nframes):
+                img = m.synth_frame(300 + i, right_view=right_view)
+                gk, gd = gpu(img)
+                ck, cd = cpu.extract(img, fast=True)
+                assert len(gk) == len(ck) and np.array_equal(gd, cd), "frame %d" % i
+                for f in ("x", "y", "response", "octave", "angle"):
+                    assert np.array_equal(gk[f], ck[f]), f
+        except Exception as e:          # surfaced in the main thread below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(rv,)) for rv in (False, True)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+
+
 def test_against_stored_golden_vectors():
     import os
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
