@@ -319,9 +319,20 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, const uint8_t* images, int nframe
     // frames are packed on the device with a 4-byte-multiple pitch
     const size_t pitch = ((size_t)width + 3) & ~(size_t)3;
     const size_t fstride = pitch * (size_t)height;
-    for (int f = 0; f < nframes; f++)
-        HIP_TRY(hipMemcpy2DAsync(c->stageImg + f * fstride, pitch, images + f * frame_stride, row_stride,
-                                 (size_t)width, (size_t)height, hipMemcpyHostToDevice, c->stream));
+    // Plain 1-D copies wherever the caller's layout allows (2-D copies from pageable memory are an order of
+    // magnitude slower): the whole batch at once, else frame by frame, else row-pitch conversion.
+    if (row_stride == pitch && frame_stride == fstride) {
+        HIP_TRY(hipMemcpyAsync(c->stageImg, images, fstride * (size_t)nframes, hipMemcpyHostToDevice, c->stream));
+    } else {
+        for (int f = 0; f < nframes; f++) {
+            if (row_stride == pitch)
+                HIP_TRY(hipMemcpyAsync(c->stageImg + f * fstride, images + f * frame_stride, fstride,
+                                       hipMemcpyHostToDevice, c->stream));
+            else
+                HIP_TRY(hipMemcpy2DAsync(c->stageImg + f * fstride, pitch, images + f * frame_stride, row_stride,
+                                         (size_t)width, (size_t)height, hipMemcpyHostToDevice, c->stream));
+        }
+    }
     rc = orbx_extract_batch_device(c, c->stageImg, nframes, width, height, pitch, fstride, c->stageKps,
                                    c->stageDesc, cap, c->stageCounts, c->stream);
     if (rc) return rc;
