@@ -462,15 +462,19 @@ extern "C" int orbx_get_level(orbx_ctx* c, int frame, int level, int border, uin
     const uint8_t* src;
     size_t stride;
     level_ptr(c, frame, level, &src, &stride);
-    std::vector<uint8_t> tmp((size_t)L.w * L.h);
-    HIP_TRY(hipMemcpy2D(tmp.data(), (size_t)L.w, src, stride, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
+    // one 1-D copy of the level with its device pitch (2-D copies into pageable memory are far slower); the
+    // last row is copied only as far as its last pixel
+    const size_t bytes = stride * (size_t)(L.h - 1) + (size_t)L.w;
+    std::vector<uint8_t> tmp(bytes);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpy(tmp.data(), src, bytes, hipMemcpyDeviceToHost));
     if (!border) {
-        for (int y = 0; y < L.h; y++) std::memcpy(dst + (size_t)y * dst_stride, tmp.data() + (size_t)y * L.w, L.w);
+        for (int y = 0; y < L.h; y++) std::memcpy(dst + (size_t)y * dst_stride, tmp.data() + (size_t)y * stride, L.w);
         return ORBX_OK;
     }
     // the 19-px BORDER_REFLECT_101 frame of src/ORBextractor.cc:1114-1120
     for (int y = 0; y < L.h + 2 * kEdge; y++) {
-        const uint8_t* S = tmp.data() + (size_t)reflect101(y - kEdge, L.h) * L.w;
+        const uint8_t* S = tmp.data() + (size_t)reflect101(y - kEdge, L.h) * stride;
         uint8_t* D = dst + (size_t)y * dst_stride;
         for (int x = 0; x < L.w + 2 * kEdge; x++) D[x] = S[reflect101(x - kEdge, L.w)];
     }
