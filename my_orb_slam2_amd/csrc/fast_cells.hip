@@ -7,14 +7,14 @@
 // the scanned rectangle as score 0, so no data crosses cells and no score map goes to HBM.
 //
 //   1. the cell's pixels (cell + 6 px) are staged in LDS as coalesced dwords;
-//   2. every scanned pixel runs a cheap antipodal-pair test (two of the eight pairs) at the low
+//   then, at iniThFAST and - only if that leaves the cell empty - again at minThFAST:
+//   2. every scanned pixel runs a cheap antipodal-pair test (two of the eight pairs) at the round's
 //      threshold; survivors are queued in LDS in row-major order (ballot + prefix count);
 //   3. queued pixels get the exact corner strength S = max over the 16 arcs of 9 of the smallest
 //      |centre - circle| with one sign; a pixel is a corner at threshold t iff S > t and its FAST
-//      score (cv cornerScore) is S - 1;
-//   4. corners above the active threshold that beat their 8 neighbours strictly are written in
-//      row-major order to the cell's slot array; if none survives at iniThFAST the same LDS score
-//      map is re-read at minThFAST.
+//      score (cv cornerScore) is S - 1; corners keep their S in an LDS score map;
+//   4. corners that beat their 8 neighbours strictly are written in row-major order to the cell's
+//      slot array.
 #include "orbx_internal.h"
 
 namespace orbx {
@@ -180,12 +180,17 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     }
     wave_sync();
 
-    // ---- 2. cheap test at the low threshold, queue survivors in row-major order ----
+    // The reference runs cv::FAST at iniThFAST and, only if that finds nothing in the cell, again at minThFAST
+    // (:801-808); so do steps 2-4. Most cells stop after the first round, whose higher threshold also lets
+    // fewer pixels through to the exact strength. The score map is still all zero when a second round starts.
+    int nout = 0;
+    for (int round = 0; round < 2; round++) {
+    const int tcur = round == 0 ? iniTh : minTh;
+    // ---- 2. cheap test at this round's threshold, queue survivors in row-major order ----
     // A lane tests four horizontally adjacent pixels per step from five LDS dwords (the row itself: the group,
     // its left and right neighbours; rows -3 and +3: the group), every byte picked by an SDWA operand select.
     // 8 lanes span a scan of up to 32 px (8 rows per step), 16 lanes a wider one (4 rows per step).
     // A queue entry is (y << 8) | x.
-    const int tlow = min(iniTh, minTh);
     const bool narrow = sw <= 32;                      // cells are < 60 px wide (width / floor(width / 30))
     const int rowsPerIter = narrow ? 8 : 4;
     const int gx = narrow ? lane & 7 : lane & 15, ly = narrow ? lane >> 3 : lane >> 4;
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
                 const int mnmax = max(min(p0, p8), min(p4, p12));
                 const int mxmin = min(max(p0, p8), max(p4, p12));
                 // compare straight into lane masks (40 = signed <, 38 = signed >); the rest is scalar
-                m[j] = (__builtin_amdgcn_sicmp(mnmax, v - tlow, 40) | __builtin_amdgcn_sicmp(mxmin, v + tlow, 38)) &
+                m[j] = (__builtin_amdgcn_sicmp(mnmax, v - tcur, 40) | __builtin_amdgcn_sicmp(mxmin, v + tcur, 38)) &
                        xm[j] & ym;
             }
             // row-major rank: everything queued by lower lanes, then this lane's own earlier pixels
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     }
     wave_sync();
 
-    // ---- 3. exact corner strength for queued pixels; keep corners (S > tlow) in order ----
+    // ---- 3. exact corner strength for queued pixels; keep corners (S > tcur) in order ----
     int nc = 0;
     for (int base = 0; base < nq; base += 64) {
         const int qi = base + lane;
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
             yx = queue[qi];
             const int y = yx >> 8, x = yx & 255;
             S = corner_strength<PITCH>(tile + (y + 3) * pitch + xo + x + 3);
-            if (S > tlow) score[(y + 1) * sp + x + 1] = (uint8_t)S; else S = 0;
+            if (S > tcur) score[(y + 1) * sp + x + 1] = (uint8_t)S; else S = 0;
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(S > 0);
         // in-place compaction: position nc+prefix <= qi, and every lane has read queue[qi] above
@@ -253,38 +258,32 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     }
     wave_sync();
 
-    // ---- 4. suppression + ordered output, iniTh first, minTh if the cell stays empty ----
-    int nout = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        const int t = pass == 0 ? iniTh : minTh;
-        for (int base = 0; base < nc; base += 64) {
-            const int qi = base + lane;
-            bool keep = false;
-            int x = 0, y = 0, sc = 0;
-            if (qi < nc) {
-                const int yx = queue[qi];
-                y = yx >> 8;
-                x = yx & 255;
-                const uint8_t* s = score + (y + 1) * sp + x + 1;
-                const int S = s[0];
-                if (S > t) {
-                    sc = S - 1;
-                    int nb = max(max(s[-1], s[1]), max(max(s[-sp - 1], s[-sp]), s[-sp + 1]));
-                    nb = max(nb, max(max(s[sp - 1], s[sp]), s[sp + 1]));
-                    // neighbours that are not corners at this threshold count as score 0
-                    const int nbScore = nb > t ? nb - 1 : 0;
-                    keep = sc > nbScore;
-                }
-            }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-            if (keep) {
-                const int pos = nout + prefix_count(m);
-                // FAST reports sub-image coordinates (x+3, y+3); the caller adds j*wCell, i*hCell (:814-815)
-                if (pos < L.slotCap) slotOut[pos] = pack_cand(cj * L.wCell + x + 3, ci * L.hCell + y + 3, sc);
-            }
-            nout += __popcll(m);
+    // ---- 4. suppression + ordered output ----
+    for (int base = 0; base < nc; base += 64) {
+        const int qi = base + lane;
+        bool keep = false;
+        int x = 0, y = 0, sc = 0;
+        if (qi < nc) {
+            const int yx = queue[qi];
+            y = yx >> 8;
+            x = yx & 255;
+            const uint8_t* s = score + (y + 1) * sp + x + 1;
+            sc = s[0] - 1;                           // every queued pixel is a corner at this threshold
+            int nb = max(max(s[-1], s[1]), max(max(s[-sp - 1], s[-sp]), s[-sp + 1]));
+            nb = max(nb, max(max(s[sp - 1], s[sp]), s[sp + 1]));
+            // the map holds S only for corners (S > threshold); everything else counts as score 0
+            keep = sc > max(nb - 1, 0);
         }
-        if (nout > 0 || iniTh == minTh) break;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) {
+            const int pos = nout + prefix_count(m);
+            // FAST reports sub-image coordinates (x+3, y+3); the caller adds j*wCell, i*hCell (:814-815)
+            if (pos < L.slotCap) slotOut[pos] = pack_cand(cj * L.wCell + x + 3, ci * L.hCell + y + 3, sc);
+        }
+        nout += __popcll(m);
+    }
+    if (nout > 0 || iniTh == minTh) break;
+    wave_sync();
     }
     if (lane == 0) *countOut = min(nout, L.slotCap);
 }
