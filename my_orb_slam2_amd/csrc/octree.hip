@@ -294,7 +294,8 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
         __syncthreads();
         for (int w = 0; w < wv; w++) incl += part[w];
     }
-    const int P = part[0] + part[1] + part[2] + part[3];
+    int P = 0;
+    for (int w = 0; w < kThreads / 64; w++) P += part[w];
     int dst = incl - mine;
     __syncthreads();
     if (P == 0) {
