@@ -25,9 +25,7 @@ namespace orbx {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kLdsPoints = 2048;  // candidates of one level held in LDS; more spill to global memory.
-                                  // Small on purpose: the kernel is latency-bound, so more resident
-                                  // workgroups per CU matter more than keeping rare big levels in LDS.
+constexpr int kBatch = 4;          // candidates a thread loads before it uses the first (hides global / LDS latency)
 
 // Inclusive scan of data[0..n) in place. `part` holds kThreads ints. All threads must call.
 // Each thread owns a run of ceil(n / 256) elements; run totals are scanned inside each wave with
@@ -131,9 +129,19 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
         // ---- speculative child counts of every split candidate ----
         for (int i = t; i < 4 * Lc; i += kThreads) cc[i] = 0;
         __syncthreads();
-        for (int p = t; p < P; p += kThreads) {
-            const int n = nid[p];
-            if (cur.cnt[n] > 1) atomicAdd(&cc[4 * n + quadrant(cand[p], cur, n)], 1);
+        // (candidates may live in global memory: kBatch independent loads are issued before the first use)
+        for (int p0 = t; p0 < P; p0 += kThreads * kBatch) {
+            int n[kBatch];
+            uint32_t c[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int p = min(p0 + k * kThreads, P - 1);
+                n[k] = nid[p];
+                c[k] = cand[p];
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; k++)
+                if (p0 + k * kThreads < P && cur.cnt[n[k]] > 1) atomicAdd(&cc[4 * n[k] + quadrant(c[k], cur, n[k])], 1);
         }
         __syncthreads();
         // ---- processing order ----
@@ -223,10 +231,21 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
         }
         __syncthreads();
         // ---- re-label the points ----
-        for (int p = t; p < P; p += kThreads) {
-            const int n = nid[p];
-            const int kp = keptPos[n];
-            nid[p] = (uint16_t)(kp >= 0 ? kp : childPos[4 * n + quadrant(cand[p], cur, n)]);
+        for (int p0 = t; p0 < P; p0 += kThreads * kBatch) {
+            int n[kBatch];
+            uint32_t c[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                const int p = min(p0 + k * kThreads, P - 1);
+                n[k] = nid[p];
+                c[k] = cand[p];
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; k++) {
+                if (p0 + k * kThreads >= P) break;
+                const int kp = keptPos[n[k]];
+                nid[p0 + k * kThreads] = (uint16_t)(kp >= 0 ? kp : childPos[4 * n[k] + quadrant(c[k], cur, n[k])]);
+            }
         }
         __syncthreads();
         const int nExp = sh[2];
@@ -242,9 +261,21 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
     int* best = cc;
     for (int i = t; i < Lc; i += kThreads) best[i] = 0;
     __syncthreads();
-    for (int p = t; p < P; p += kThreads)
-        atomicMax(reinterpret_cast<unsigned*>(&best[nid[p]]),
-                  ((unsigned)cand_score(cand[p]) << 24) | (0xFFFFFFu - (unsigned)p));
+    for (int p0 = t; p0 < P; p0 += kThreads * kBatch) {
+        int n[kBatch];
+        uint32_t c[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const int p = min(p0 + k * kThreads, P - 1);
+            n[k] = nid[p];
+            c[k] = cand[p];
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++)
+            if (p0 + k * kThreads < P)
+                atomicMax(reinterpret_cast<unsigned*>(&best[n[k]]),
+                          ((unsigned)cand_score(c[k]) << 24) | (0xFFFFFFu - (unsigned)(p0 + k * kThreads)));
+    }
     __syncthreads();
     for (int i = t; i < Lc; i += kThreads) {
         const unsigned p = 0xFFFFFFu - ((unsigned)best[i] & 0xFFFFFFu);
@@ -256,9 +287,8 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
 }  // namespace
 
 size_t octree_lds_bytes(const PyramidGeom& g) {
-    // 12 shorts + 10 ints per node, scan scratch, scalars, then the LDS candidate arrays
-    return (size_t)g.nodeCap * (12 * 2 + 10 * 4) + (kThreads + 8) * 4 + 16 +
-           (size_t)kLdsPoints * (4 + 2);
+    // 12 shorts + 10 ints per node, scan scratch, scalars
+    return (size_t)g.nodeCap * (12 * 2 + 10 * 4) + (kThreads + 8) * 4 + 16;
 }
 
 __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGeom g) {
@@ -274,7 +304,6 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
         return;
     }
     // ---- gather the level's candidates in the reference's order: cells row-major (:781-821) ----
-    const size_t nodeBytes = ((size_t)g.nodeCap * (12 * 2 + 10 * 4) + (kThreads + 8) * 4 + 15) & ~(size_t)15;
     int* part = reinterpret_cast<int*>(smem);            // scan scratch, reused by distribute()
     const int32_t* counts = fs.cellCount + (long long)f * g.totalCells + L.cellBase;
     const uint32_t* slots = fs.slots + (long long)f * g.totalSlots + L.slotBase;
@@ -302,16 +331,11 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
         if (t == 0) *selCountOut = 0;
         return;
     }
-    uint32_t* cand;
-    uint16_t* nid;
-    const bool inLds = P <= kLdsPoints;
-    if (inLds) {
-        cand = reinterpret_cast<uint32_t*>(smem + nodeBytes);
-        nid = reinterpret_cast<uint16_t*>(smem + nodeBytes + (size_t)kLdsPoints * 4);
-    } else {
-        cand = fs.cand + (long long)f * g.totalSlots + L.slotBase;
-        nid = fs.nid + (long long)f * g.totalSlots + L.slotBase;
-    }
+    // The gathered list and the node index of every candidate stay in global memory (they are L2 hits):
+    // keeping them in LDS was no faster, and the smaller LDS footprint lets workgroups of the kernels queued
+    // on other streams share the CU while this latency-bound kernel waits.
+    uint32_t* cand = fs.cand + (long long)f * g.totalSlots + L.slotBase;
+    uint16_t* nid = fs.nid + (long long)f * g.totalSlots + L.slotBase;
     for (int c = cb; c < ce; c++) {
         const int n = counts[c];
         const uint32_t* src = slots + (long long)c * L.slotCap;
@@ -327,10 +351,7 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
         }
     }
     __syncthreads();
-    if (inLds)
-        distribute(cand, nid, P, L, g.nodeCap, smem, selOut, selCountOut);
-    else
-        distribute(cand, nid, P, L, g.nodeCap, smem, selOut, selCountOut);
+    distribute(cand, nid, P, L, g.nodeCap, smem, selOut, selCountOut);
 }
 
 hipError_t launch_octree(const FrameSet& fs, const PyramidGeom& g, int nframes, hipStream_t s) {

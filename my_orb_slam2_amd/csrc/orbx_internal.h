@@ -60,8 +60,8 @@ struct FrameSet {
     uint8_t* pyr;           // levels >= 1
     int32_t* cellCount;     // [frame][totalCells]
     uint32_t* slots;        // [frame][totalSlots] packed candidates, grouped per cell
-    uint32_t* cand;         // [frame][totalSlots] candidates of a level in reference order (spill space)
-    uint16_t* nid;          // [frame][totalSlots] quadtree node of each candidate (spill space)
+    uint32_t* cand;         // [frame][totalSlots] candidates of a level gathered in reference order
+    uint16_t* nid;          // [frame][totalSlots] quadtree node of each candidate
     uint32_t* sel;          // [frame][totalSel] packed selected keypoints
     int32_t* selCount;      // [frame][nlevels]
 };
