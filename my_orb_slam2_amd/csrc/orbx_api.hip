@@ -191,7 +191,8 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_ctx** out) {
     if ((rc = dev_alloc(&c->fs.cand, B * (size_t)mg.totalSlots))) return fail(rc);
     if ((rc = dev_alloc(&c->fs.nid, B * (size_t)mg.totalSlots))) return fail(rc);
     if ((rc = dev_alloc(&c->fs.sel, B * (size_t)mg.totalSel))) return fail(rc);
-    if ((rc = dev_alloc(&c->fs.selCount, B * (size_t)cfg->nlevels))) return fail(rc);
+    if ((rc = dev_alloc(&c->fs.selCount, 2 * B * (size_t)cfg->nlevels))) return fail(rc);
+    c->fs.selBefore = c->fs.selCount + B * (size_t)cfg->nlevels;
     *out = c;
     return ORBX_OK;
 }

@@ -64,6 +64,7 @@ struct FrameSet {
     uint16_t* nid;          // [frame][totalSlots] quadtree node of each candidate
     uint32_t* sel;          // [frame][totalSel] packed selected keypoints
     int32_t* selCount;      // [frame][nlevels]
+    int32_t* selBefore;     // [frame][nlevels] keypoints of the frame's lower levels (exclusive prefix of selCount)
 };
 
 // Bilinear resize tables of one level (cv::resize INTER_LINEAR, 8U fixed point).

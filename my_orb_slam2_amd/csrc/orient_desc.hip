@@ -169,22 +169,30 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 // sin and cos of x in [0, 8] to within an ulp of double (the reference takes cos/sin of the angle in double and
 // rounds to float, src/ORBextractor.cc:103-104). Quadrant reduction with a two-part pi/2, then the
 // minimax polynomials of fdlibm's __kernel_sin / __kernel_cos on |r| <= pi/4.
+// a * b + k with the constant k held in scalar registers (v_fma_f64 takes one SGPR source; left to itself the
+// compiler picks v_fmac_f64 and spends two v_mov per coefficient to seed the accumulator)
+__device__ __forceinline__ double fma_k(double a, double b, double k) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+
 __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
     const double kq = __builtin_rint(x * 6.36619772367581382433e-01);             // x * 2/pi, 0..5
     double r = __builtin_fma(-kq, 1.57079632679489655800e+00, x);
     r = __builtin_fma(-kq, 6.12323399573676603587e-17, r);
     const double z = r * r;
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    double ps = fma_k(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma_k(z, ps, 2.75573137070700676789e-06);
+    ps = fma_k(z, ps, -1.98412698298579493134e-04);
+    ps = fma_k(z, ps, 8.33333333332248946124e-03);
+    ps = fma_k(z, ps, -1.66666666666666324348e-01);
     const double sn = __builtin_fma(z * r, ps, r);
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    double pc = fma_k(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma_k(z, pc, -2.75573143513906633035e-07);
+    pc = fma_k(z, pc, 2.48015872894767294178e-05);
+    pc = fma_k(z, pc, -1.38888888888741095749e-03);
+    pc = fma_k(z, pc, 4.16666666666666019037e-02);
     const double hz = 0.5 * z, w = 1.0 - hz;
     const double cs = w + (((1.0 - w) - hz) + z * z * pc);
     const int n = (int)kq;
@@ -216,7 +224,7 @@ __device__ __forceinline__ uint32_t pack4_sat(const uint4& v) {
     uint32_t lo, hi;
     asm("v_sat_pk_u8_i16 %0, %1" : "=v"(lo) : "v"(__builtin_amdgcn_perm(v.y, v.x, 0x07060302u)));
     asm("v_sat_pk_u8_i16 %0, %1" : "=v"(hi) : "v"(__builtin_amdgcn_perm(v.w, v.z, 0x07060302u)));
-    return (lo & 0xffffu) | (hi << 16);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);   // low halves of lo and hi
 }
 
 __device__ __forceinline__ uint32_t row_sum4(uint32_t x, uint32_t klo, uint32_t khi, uint32_t y) {
@@ -224,6 +232,19 @@ __device__ __forceinline__ uint32_t row_sum4(uint32_t x, uint32_t klo, uint32_t 
 }
 
 }  // namespace
+
+// Exclusive prefix of every frame's per-level keypoint counts, and the frame totals the caller receives.
+__global__ __launch_bounds__(64) void sel_prefix_kernel(FrameSet fs, int nlevels, int nframes,
+                                                        int32_t* __restrict__ countsOut) {
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= nframes) return;
+    int run = 0;
+    for (int l = 0; l < nlevels; l++) {
+        fs.selBefore[(long long)f * nlevels + l] = run;
+        run += fs.selCount[(long long)f * nlevels + l];
+    }
+    countsOut[f] = run;
+}
 
 template <bool ALIGNED4>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameSet fs, PyramidGeom g,
@@ -240,20 +261,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     momw[threadIdx.x] = reinterpret_cast<const uint2*>(&c_momw.w[0][0][0])[threadIdx.x];
     __syncthreads();                              // the only block-wide step; waves are independent after it
     if (slot >= g.totalSel) return;
+    // fetched together with the counts below (the slot exists even when it holds no keypoint), so the patch
+    // loads wait for one round trip instead of two
+    const uint32_t packed = fs.sel[(long long)f * g.totalSel + slot];
     int l = 0;
     while (l + 1 < g.nlevels && slot >= g.lv[l + 1].selBase) l++;
     const int k = slot - g.lv[l].selBase;
-    const int32_t* selCount = fs.selCount + (long long)f * g.nlevels;
-    // position in the frame's output: levels are concatenated in order (:1067-1096)
-    int before = 0, total = 0;
-    for (int i = 0; i < g.nlevels; i++) {
-        const int c = selCount[i];
-        before += i < l ? c : 0;
-        total += c;
-    }
-    if (slot == 0 && lane == 0) countsOut[f] = total;
-    const int outIdx = before + k;
-    if (k >= selCount[l] || outIdx >= cap) return;
+    // position in the frame's output: levels are concatenated in order (:1067-1096); sel_prefix_kernel has
+    // summed the lower levels, so a wave needs two loads instead of one per level
+    const int mine = fs.selCount[(long long)f * g.nlevels + l];
+    const int outIdx = fs.selBefore[(long long)f * g.nlevels + l] + k;
+    if (k >= mine || outIdx >= cap) return;
     const LevelGeom& L = g.lv[l];
     uint8_t* R = s_mem + wv * kWaveLds;                                        // raw patch, later Bl
     uint8_t* Tb = R + kRowsAlloc * kRPitch;                                    // packed row sums
@@ -269,7 +287,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
 #pragma unroll
     for (int q = 0; q < 4; q++) patv[q] = reinterpret_cast<const float4*>(c_patternf_tab.v)[64 * q + lane];
 
-    const uint32_t packed = fs.sel[(long long)f * g.totalSel + slot];
     const int kx = cand_x(packed) + kBorder;   // level coordinates (:835-836)
     const int ky = cand_y(packed) + kBorder;
     const uint8_t* img;
@@ -459,6 +476,7 @@ __global__ __launch_bounds__(256) void blur_level_kernel(const uint8_t* __restri
 
 hipError_t launch_orient_desc(const FrameSet& fs, const PyramidGeom& g, int nframes, int blurTaps,
                               orbx_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, hipStream_t s) {
+    hipLaunchKernelGGL(sel_prefix_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, fs, g.nlevels, nframes, counts);
     dim3 grid(nframes, (g.totalSel + kWavesPerBlock - 1) / kWavesPerBlock, 1), block(64 * kWavesPerBlock, 1, 1);
     const bool aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
     if (aligned)
