@@ -52,11 +52,12 @@ constexpr int kPR = 21;                 // patch radius
 constexpr int kRowsAlloc = 44;          // 43 patch rows, staged in fours; Bl row 37 also lands in the spare row
 constexpr int kRPitch = 48;             // bytes per raw row (12 dwords)
 constexpr int kCx = 23;                 // LDS column of the keypoint
-constexpr int kTPitch = 44;             // dwords per packed row pair of T, bytes per row of Bl
+constexpr int kTPitch = 44;             // bytes per row of Bl (columns 0..43 of the patch)
+constexpr int kTDw = 40;                // dwords per packed row pair of T: column groups 1..10 only
 constexpr int kTPairs = 22;             // row pairs of T (43 rows)
 constexpr int kBlRows = 37;             // blurred rows: patch rows 3..39
 constexpr int kWavesPerBlock = 4;
-constexpr int kWaveLds = kRowsAlloc * kRPitch + kTPairs * kTPitch * 4;  // 2112 + 3872 bytes
+constexpr int kWaveLds = kRowsAlloc * kRPitch + kTPairs * kTDw * 4;  // 2112 + 3520 bytes
 constexpr int kHIters = 3, kVIters = 3; // 64-item rounds of the row pass and of the column pass
 
 // Byte weights for the intensity-centroid sums, four columns per dword: patch row v + 15 (32, the last
@@ -122,14 +123,14 @@ constexpr ItemTables make_item_tables() {
         for (int gg = 1; gg <= 10; gg++)
             if (rowsum_group_needed(2 * j, gg) || rowsum_group_needed(2 * j + 1, gg)) {
                 if (nh < kHIters * 64)
-                    t.h[nh] = (uint32_t)(2 * j * kRPitch + (gg - 1) * 4) | (uint32_t)((j * kTPitch + 4 * gg) * 4) << 16;
+                    t.h[nh] = (uint32_t)(2 * j * kRPitch + (gg - 1) * 4) | (uint32_t)((j * kTDw + 4 * (gg - 1)) * 4) << 16;
                 nh++;
             }
     for (int p = 0; 2 * p < kBlRows; p++)
         for (int gg = 1; gg <= 10; gg++)
             if (blur_group_needed(2 * p, gg) || blur_group_needed(2 * p + 1, gg)) {
                 if (nv < kVIters * 64)
-                    t.v[nv] = (uint32_t)((p * kTPitch + 4 * gg) * 4) | (uint32_t)(2 * p * kTPitch + 4 * gg) << 16;
+                    t.v[nv] = (uint32_t)((p * kTDw + 4 * (gg - 1)) * 4) | (uint32_t)(2 * p * kTPitch + 4 * gg) << 16;
                 nv++;
             }
     t.nh = nh;
@@ -142,7 +143,6 @@ constexpr ItemTables kItems = make_item_tables();
 static_assert(kItems.nh <= kHIters * 64 && kItems.nv <= kVIters * 64, "work item tables overflow");
 __device__ const ItemTables c_items = make_item_tables();
 
-constexpr int kMomLds = 32 * 8 * 2 * 4;   // moment weights, shared by the block
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     p = p < 0 ? -p : p;
@@ -246,21 +246,20 @@ __global__ __launch_bounds__(64) void sel_prefix_kernel(FrameSet fs, int nlevels
     countsOut[f] = run;
 }
 
+// 22.5 KB of LDS per workgroup lets seven workgroups share a CU; seven waves per SIMD need <= 72 VGPRs, which is
+// why the pattern rows are fetched only after the row pass.
 template <bool ALIGNED4>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameSet fs, PyramidGeom g,
                                                                            int blurTaps,
                                                                            orbx_keypoint* __restrict__ kpsOut,
                                                                            uint8_t* __restrict__ descOut, int cap,
                                                                            int32_t* __restrict__ countsOut) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kWavesPerBlock * kWaveLds + kMomLds];
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kWavesPerBlock * kWaveLds];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the set-up scalar
     const int f = blockIdx.x;                     // frame-fastest grid: one frame per XCD
     const int slot = blockIdx.y * kWavesPerBlock + wv;    // index into the frame's selected regions
-    uint2* momw = reinterpret_cast<uint2*>(s_mem + kWavesPerBlock * kWaveLds);
-    momw[threadIdx.x] = reinterpret_cast<const uint2*>(&c_momw.w[0][0][0])[threadIdx.x];
-    __syncthreads();                              // the only block-wide step; waves are independent after it
-    if (slot >= g.totalSel) return;
+    if (slot >= g.totalSel) return;               // the waves of a block never synchronise with each other
     // fetched together with the counts below (the slot exists even when it holds no keypoint), so the patch
     // loads wait for one round trip instead of two
     const uint32_t packed = fs.sel[(long long)f * g.totalSel + slot];
@@ -283,9 +282,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     for (int q = 0; q < kHIters; q++) hItem[q] = c_items.h[64 * q + lane];
 #pragma unroll
     for (int q = 0; q < kVIters; q++) vItem[q] = c_items.v[64 * q + lane];
-    float4 patv[4];                                // this lane's four pattern pairs, fetched just as early
+    uint2 momw[4];                                 // this lane's intensity-centroid weights, fetched just as early
 #pragma unroll
-    for (int q = 0; q < 4; q++) patv[q] = reinterpret_cast<const float4*>(c_patternf_tab.v)[64 * q + lane];
+    for (int q = 0; q < 4; q++) momw[q] = reinterpret_cast<const uint2*>(&c_momw.w[0][0][0])[64 * q + lane];
 
     const int kx = cand_x(packed) + kBorder;   // level coordinates (:835-836)
     const int ky = cand_y(packed) + kBorder;
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t D = Rw[q * 8 * 12];
-            const uint2 w = momw[lane + 64 * q];
+            const uint2 w = momw[q];
             const uint32_t rs = __builtin_amdgcn_udot4(D, w.x, 0u, false);
             s0 += (int)rs;
             m01 += __mul24((lane >> 3) + 8 * q - kHalfPatch, (int)rs);
@@ -382,6 +381,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     }
     wave_sync();
 
+    float4 patv[4];                                // this lane's four pattern pairs; they arrive during the column pass
+#pragma unroll
+    for (int q = 0; q < 4; q++) patv[q] = reinterpret_cast<const float4*>(c_patternf_tab.v)[64 * q + lane];
+
     // ---- column pass: Bl[y][j] = min(255, (sum_r K[r] * T[y+r][j] + 32768) >> 16), y = patch row - 3 ----
     {
         const uint32_t k2 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 49u : 48u, k3 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 55u : 56u;
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
             uint4 e = make_uint4(32768u, 32768u, 32768u, 32768u), o = e;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint4 t = *reinterpret_cast<const uint4*>(tp + r * kTPitch * 4);
+                const uint4 t = *reinterpret_cast<const uint4*>(tp + r * kTDw * 4);
                 const us2 a = __builtin_bit_cast(us2, we[r]), b = __builtin_bit_cast(us2, wo[r]);
                 e.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), a, e.x, false);
                 e.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), a, e.y, false);
