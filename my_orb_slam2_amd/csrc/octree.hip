@@ -25,7 +25,7 @@ namespace orbx {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kBatch = 4;          // candidates a thread loads before it uses the first (hides global / LDS latency)
+constexpr int kBatch = 4;          // candidates a thread loads before it uses the first (hides the memory latency)
 
 // Inclusive scan of data[0..n) in place. `part` holds kThreads ints. All threads must call.
 // Each thread owns a run of ceil(n / 256) elements; run totals are scanned inside each wave with
@@ -67,7 +67,7 @@ __device__ __forceinline__ int quadrant(uint32_t c, const Nodes& nd, int n) {
     return (cand_x(c) < xm ? 0 : 1) + (cand_y(c) < ym ? 0 : 2);   // n1, n2, n3, n4 (:507-517)
 }
 
-// The whole selection for one level, with candidates at `cand` / `nid` (LDS or global).
+// The whole selection for one level, with the level's candidates at `cand` and their node indices at `nid`.
 __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom& L, int nodeCap,
                            uint8_t* lds, uint32_t* selOut, int32_t* selCountOut) {
     const int t = threadIdx.x;
