@@ -299,11 +299,23 @@ __global__ __launch_bounds__(256) void stereo_band_kernel(int cap, const orbx_ke
     }
 }
 
+// Sum over the wave; every lane must be active. The total is returned to all lanes.
+__device__ __forceinline__ int wave_sum_i32(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false);  // row_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast15
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast31
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
 // Second half of Frame::ComputeStereoMatches (src/Frame.cc:589-661): for every left keypoint whose
 // band match is closer than (TH_HIGH + TH_LOW) / 2, slide an 11x11 window +-5 px along the row of the
 // right pyramid level, keep the offset with the smallest sum of absolute differences of the
 // centre-subtracted patches, fit a parabola through its neighbours and turn the sub-pixel column into
-// uRight and depth. One thread per left keypoint. sadDist receives the winning SAD (or -1).
+// uRight and depth. One wave per left keypoint: a lane owns two of the 121 window positions, the eleven
+// sums are wave reductions, everything after them is wave-uniform. sadDist receives the winning SAD (or -1).
 __global__ __launch_bounds__(256) void stereo_refine_kernel(int cap, PyramidView left, PyramidView right,
                                                             const orbx_keypoint* __restrict__ kl,
                                                             const int32_t* __restrict__ nl,
@@ -315,7 +327,8 @@ __global__ __launch_bounds__(256) void stereo_refine_kernel(int cap, PyramidView
                                                             float* __restrict__ uRight, float* __restrict__ depth,
                                                             int32_t* __restrict__ sadDist) {
     const int pair = blockIdx.y;
-    const int iL = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (iL >= cap) return;
     const long long o = (long long)pair * cap;
     float outU = -1.0f, outZ = -1.0f;
@@ -336,22 +349,34 @@ __global__ __launch_bounds__(256) void stereo_refine_kernel(int cap, PyramidView
         const bool inside = cv - w >= 0 && cv + w < A.h && cv + w < B.h && cu - w >= 0 && cu + w < A.w &&
                             cr - Lr - w >= 0 && cr + Lr + w < B.w;
         if (!(iniu < 0 || endu >= (float)B.w) && inside) {     // (:612-613)
-            const uint8_t* pa = A.base + (long long)pair * A.frameStride;
-            const uint8_t* pb = B.base + (long long)pair * B.frameStride;
-            const int cL = pa[(long long)cv * A.rowStride + cu];
+            const uint8_t* pa = A.base + (long long)pair * A.frameStride + (long long)cv * A.rowStride + cu;
+            const uint8_t* pb = B.base + (long long)pair * B.frameStride + (long long)cv * B.rowStride + cr;
+            // window positions lane and lane + 64 (row-major 11 x 11; position 60 is the centre); lanes past
+            // 120 repeat position 120 with weight 0
+            const int i0 = lane, i1 = min(lane + 64, 120);
+            const int dy0 = i0 / 11 - w, dx0 = i0 - (dy0 + w) * 11 - w;
+            const int dy1 = i1 / 11 - w, dx1 = i1 - (dy1 + w) * 11 - w;
+            const bool two = lane + 64 <= 120;
+            const int cL = pa[0];
+            const int a0 = (int)pa[(long long)dy0 * A.rowStride + dx0] - cL;
+            const int a1 = (int)pa[(long long)dy1 * A.rowStride + dx1] - cL;
+            const uint8_t* rb0 = pb + (long long)dy0 * B.rowStride + dx0;
+            const uint8_t* rb1 = pb + (long long)dy1 * B.rowStride + dx1;
+            int rv0[11], rv1[11];
+#pragma unroll
+            for (int k = 0; k < 11; k++) {              // all loads first: their latencies overlap
+                rv0[k] = rb0[k - Lr];
+                rv1[k] = rb1[k - Lr];
+            }
             int dists[11];
             int best = INT32_MAX, bestInc = 0;
-            for (int inc = -Lr; inc <= Lr; inc++) {
-                const int cR = pb[(long long)cv * B.rowStride + cr + inc];
-                int sad = 0;
-                for (int dy = -w; dy <= w; dy++) {
-                    const uint8_t* ra = pa + (long long)(cv + dy) * A.rowStride + cu;
-                    const uint8_t* rb = pb + (long long)(cv + dy) * B.rowStride + cr + inc;
 #pragma unroll
-                    for (int dx = -w; dx <= w; dx++) sad += abs(((int)ra[dx] - cL) - ((int)rb[dx] - cR));
-                }
-                dists[inc + Lr] = sad;
-                if (sad < best) { best = sad; bestInc = inc; }           // float compare of exact integers (:622)
+            for (int k = 0; k < 11; k++) {
+                const int cR = pb[k - Lr];               // wave-uniform
+                const int part = abs(a0 - (rv0[k] - cR)) + (two ? abs(a1 - (rv1[k] - cR)) : 0);
+                const int sad = wave_sum_i32(part);
+                dists[k] = sad;
+                if (sad < best) { best = sad; bestInc = k - Lr; }           // float compare of exact integers (:622)
             }
             if (bestInc != -Lr && bestInc != Lr) {                      // (:631)
                 float d1 = 0.f, d2 = 0.f, d3 = 0.f;
@@ -379,9 +404,11 @@ __global__ __launch_bounds__(256) void stereo_refine_kernel(int cap, PyramidView
             }
         }
     }
-    uRight[o + iL] = outU;
-    depth[o + iL] = outZ;
-    sadDist[o + iL] = outD;
+    if (lane == 0) {
+        uRight[o + iL] = outU;
+        depth[o + iL] = outZ;
+        sadDist[o + iL] = outD;
+    }
 }
 
 // Outlier cut of src/Frame.cc:663-676, one workgroup per pair: median SAD of the accepted matches (the
@@ -527,7 +554,7 @@ hipError_t launch_stereo_refine(int npairs, int cap, const PyramidView& left, co
                                 const float* invScale, float bf, float maxD, float* uRight, float* depth,
                                 int32_t* sadDist, hipStream_t s) {
     if (npairs <= 0 || cap <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stereo_refine_kernel, dim3((cap + 255) / 256, npairs, 1), dim3(256), 0, s, cap, left, right,
+    hipLaunchKernelGGL(stereo_refine_kernel, dim3((cap + 3) / 4, npairs, 1), dim3(256), 0, s, cap, left, right,
                        kl, nl, kr, bestIdx, bestDist, scale, invScale, bf, maxD, uRight, depth, sadDist);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
