@@ -21,12 +21,33 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--reuse", action="store_true",
+                    help="one context sized 1000 x 800 for all cases (image sizes change from call to call, batches of 1-3)")
     a = ap.parse_args()
     import my_orb_slam2_amd as m
     from my_orb_slam2_amd import synth as S
     from tests import oracle as orc
     rng = np.random.default_rng(a.seed)
     total_kp = 0
+    if a.reuse:
+        gpu = m.ORBextractor(700, 1.2, 8, 20, 7, max_width=1000, max_height=800, max_batch=3)
+        cpu = orc.Extractor(700, 1.2, 8, 20, 7)
+        for case in range(a.cases):
+            w, h, b = int(rng.integers(70, 1001)), int(rng.integers(70, 801)), int(rng.integers(1, 4))
+            frames = m.synth_batch(5000 + 3 * case, b, w, h)
+            if rng.random() < 0.2:
+                frames[0] = m.synth_frame(case, w, h, kind=S.NOISE)
+            got = gpu.extract_batch(frames) if b > 1 or rng.random() < 0.5 else [gpu(frames[0])]
+            for i, (gk, gd) in enumerate(got):
+                ck, cd = cpu.extract(frames[i], fast=True)
+                ok = len(gk) == len(ck) and all(np.array_equal(gk[f], ck[f]) for f in ("x", "y", "size", "response", "octave", "angle"))
+                if not (ok and np.array_equal(gd, cd)):
+                    print("FAIL (reused context):", json.dumps(dict(case=case, w=w, h=h, batch=b, frame=i)), len(gk), len(ck))
+                    sys.exit(1)
+                total_kp += len(ck)
+        print(json.dumps({"cases": a.cases, "seed": a.seed, "mode": "one context, changing sizes", "keypoints_compared": total_kp,
+                          "differences": 0}))
+        return
     for case in range(a.cases):
         w = int(rng.integers(70, 1000))
         h = int(rng.integers(70, 800))
