@@ -229,6 +229,15 @@ def main():
                      "path_achieved": round(BYTES_PER_FRAME * fps / world / 1e9, 2),
                      "path_frac": round(BYTES_PER_FRAME * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
     }
+    if valu:
+        # The kernel's real limiter: wave64 VALU instructions (PMC count for this workload, profiles/valu.json)
+        # over the live kernel time, against 256 CUs x 4 SIMDs issuing one instruction per 4 cycles at 2.4 GHz.
+        issue_peak = 256 * 4 * 2.4e9 / 4
+        issue_rate = valu["valu_insts_per_launch"] / (acc[dom] * 1e-3)
+        out["roofline_valu"] = {"bound": "valu-issue", "kernel": dom, "achieved": round(issue_rate / 1e9, 2),
+                                "peak": round(issue_peak / 1e9, 2), "unit": "G wave64-instructions/s",
+                                "frac": round(issue_rate / issue_peak, 4),
+                                "frac_of_kernel_cycles": valu["valu_issue_frac"]}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, host[:64])
         out["gpu_over_cpu_all_cores"] = round(fps / out["cpu_baseline"]["value"], 1)
