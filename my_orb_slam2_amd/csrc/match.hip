@@ -475,6 +475,9 @@ inline int64_t pick_chunk_rows(int64_t nq, int64_t ndb) {
     int64_t rows = (ndb + want - 1) / want;
     if (rows < 2048) rows = 2048;                            // keep the fold cheap
     if (rows > kMaxChunkRows) rows = kMaxChunkRows;
+    // equal chunks: a short last chunk would leave most of the chip idle while the long ones finish
+    const int64_t nchunks = ndb > 0 ? (ndb + rows - 1) / rows : 1;
+    if (ndb > 0) rows = (ndb + nchunks - 1) / nchunks;
     return rows;
 }
 }  // namespace
