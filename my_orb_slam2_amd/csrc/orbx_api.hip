@@ -34,10 +34,14 @@ struct orbx_ctx {
     // device buffers sized for max_width x max_height x max_batch
     PyramidGeom maxGeom;
     FrameSet fs;
-    uint8_t* stageImg = nullptr;        // H2D staging of host frames
-    orbx_keypoint* stageKps = nullptr;  // device outputs of the host-buffer entry points
-    uint8_t* stageDesc = nullptr;
-    int32_t* stageCounts = nullptr;
+    // Host-buffer entry points: frames go through stageImg; counts, keypoints and descriptors of a call are
+    // packed into one device block (stageOut) that comes back in one copy to its pinned twin (pinOut). Small
+    // inputs are packed into pinned memory first (pinIn), whatever the caller's strides.
+    uint8_t* stageImg = nullptr;
+    uint8_t* stageOut = nullptr;
+    uint8_t* pinOut = nullptr;
+    uint8_t* pinIn = nullptr;
+    size_t pinInBytes = 0;
     int stageCap = 0;
     // last call
     int lastFrames = 0;
@@ -201,9 +205,11 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->fs.pyr, c->fs.cellCount, c->fs.slots, c->fs.cand, c->fs.nid, c->fs.sel,
-                    c->fs.selCount, c->resizeBlob, c->stageImg, c->stageKps, c->stageDesc, c->stageCounts};
+                    c->fs.selCount, c->resizeBlob, c->stageImg, c->stageOut};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
+    if (c->pinOut) (void)hipHostFree(c->pinOut);
+    if (c->pinIn) (void)hipHostFree(c->pinIn);
     for (hipEvent_t e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -280,23 +286,44 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, i
 }
 
 namespace {
+constexpr size_t kPinInMax = 16u << 20;   // inputs up to this size are packed through pinned memory
+
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Offsets of the three outputs of one call inside the output block.
+struct OutLayout {
+    size_t kps, desc, total;
+    OutLayout(size_t nframes, size_t cap) {
+        kps = up256(nframes * sizeof(int32_t));
+        desc = kps + up256(nframes * cap * sizeof(orbx_keypoint));
+        total = desc + nframes * cap * ORBX_DESC_BYTES;
+    }
+};
+
 int ensure_staging(orbx_ctx* c, int cap) {
     const size_t B = (size_t)c->cfg.max_batch;
     if (!c->stageImg) {
-        int rc = dev_alloc(&c->stageImg, B * (((size_t)c->cfg.max_width + 3) & ~(size_t)3) * c->cfg.max_height);
+        const size_t all = B * (((size_t)c->cfg.max_width + 3) & ~(size_t)3) * c->cfg.max_height;
+        int rc = dev_alloc(&c->stageImg, all);
         if (rc) return rc;
-        if ((rc = dev_alloc(&c->stageCounts, B))) return rc;
+        void* p = nullptr;
+        c->pinInBytes = std::min(all, kPinInMax);
+        HIP_TRY(hipHostMalloc(&p, c->pinInBytes, hipHostMallocDefault));
+        c->pinIn = static_cast<uint8_t*>(p);
     }
     if (cap > c->stageCap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->stageKps) HIP_TRY(hipFree(c->stageKps));
-        if (c->stageDesc) HIP_TRY(hipFree(c->stageDesc));
-        c->stageKps = nullptr;
-        c->stageDesc = nullptr;
+        if (c->stageOut) HIP_TRY(hipFree(c->stageOut));
+        c->stageOut = nullptr;
+        if (c->pinOut) HIP_TRY(hipHostFree(c->pinOut));
+        c->pinOut = nullptr;
         c->stageCap = 0;
-        int rc = dev_alloc(&c->stageKps, B * (size_t)cap);
+        const OutLayout lay(B, (size_t)cap);
+        int rc = dev_alloc(&c->stageOut, lay.total);
         if (rc) return rc;
-        if ((rc = dev_alloc(&c->stageDesc, B * (size_t)cap * ORBX_DESC_BYTES))) return rc;
+        void* p = nullptr;
+        HIP_TRY(hipHostMalloc(&p, lay.total, hipHostMallocDefault));
+        c->pinOut = static_cast<uint8_t*>(p);
         c->stageCap = cap;
     }
     return ORBX_OK;
@@ -320,29 +347,56 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, const uint8_t* images, int nframe
     // frames are packed on the device with a 4-byte-multiple pitch
     const size_t pitch = ((size_t)width + 3) & ~(size_t)3;
     const size_t fstride = pitch * (size_t)height;
-    // Plain 1-D copies wherever the caller's layout allows (2-D copies from pageable memory are an order of
-    // magnitude slower): the whole batch at once, else frame by frame, else row-pitch conversion.
-    if (row_stride == pitch && frame_stride == fstride) {
-        HIP_TRY(hipMemcpyAsync(c->stageImg, images, fstride * (size_t)nframes, hipMemcpyHostToDevice, c->stream));
+    const size_t tail = pitch - (size_t)width;      // the last row of the caller's buffer may end at `width`
+    if (fstride * (size_t)nframes <= c->pinInBytes) {
+        // Small input (the one-frame-per-call case above all): repack into pinned memory on the host, whatever
+        // the caller's strides, and send it with one asynchronous copy. The previous call has been waited for,
+        // so the pinned buffer is free.
+        if (row_stride == pitch && frame_stride == fstride) {
+            std::memcpy(c->pinIn, images, fstride * (size_t)nframes - tail);
+        } else {
+            for (int f = 0; f < nframes; f++) {
+                const uint8_t* src = images + (size_t)f * frame_stride;
+                uint8_t* dst = c->pinIn + (size_t)f * fstride;
+                if (row_stride == pitch) {
+                    std::memcpy(dst, src, fstride - tail);
+                } else {
+                    for (int y = 0; y < height; y++) std::memcpy(dst + y * pitch, src + y * row_stride, (size_t)width);
+                }
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(c->stageImg, c->pinIn, fstride * (size_t)nframes, hipMemcpyHostToDevice, c->stream));
+    } else if (row_stride == pitch && frame_stride == fstride) {
+        // Large input: plain 1-D copies wherever the caller's layout allows (2-D copies from pageable memory are
+        // an order of magnitude slower): the whole batch at once, else frame by frame, else row-pitch conversion.
+        HIP_TRY(hipMemcpyAsync(c->stageImg, images, fstride * (size_t)nframes - tail, hipMemcpyHostToDevice, c->stream));
     } else {
         for (int f = 0; f < nframes; f++) {
             if (row_stride == pitch)
-                HIP_TRY(hipMemcpyAsync(c->stageImg + f * fstride, images + f * frame_stride, fstride,
+                HIP_TRY(hipMemcpyAsync(c->stageImg + f * fstride, images + f * frame_stride, fstride - tail,
                                        hipMemcpyHostToDevice, c->stream));
             else
                 HIP_TRY(hipMemcpy2DAsync(c->stageImg + f * fstride, pitch, images + f * frame_stride, row_stride,
                                          (size_t)width, (size_t)height, hipMemcpyHostToDevice, c->stream));
         }
     }
-    rc = orbx_extract_batch_device(c, c->stageImg, nframes, width, height, pitch, fstride, c->stageKps,
-                                   c->stageDesc, cap, c->stageCounts, c->stream);
+    const OutLayout lay((size_t)nframes, (size_t)cap);
+    rc = orbx_extract_batch_device(c, c->stageImg, nframes, width, height, pitch, fstride,
+                                   reinterpret_cast<orbx_keypoint*>(c->stageOut + lay.kps), c->stageOut + lay.desc, cap,
+                                   reinterpret_cast<int32_t*>(c->stageOut), c->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(counts, c->stageCounts, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(kps, c->stageKps, sizeof(orbx_keypoint) * (size_t)nframes * cap,
-                           hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(desc, c->stageDesc, (size_t)ORBX_DESC_BYTES * nframes * cap, hipMemcpyDeviceToHost,
-                           c->stream));
+    HIP_TRY(hipMemcpyAsync(c->pinOut, c->stageOut, lay.total, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    // only the keypoints that exist are handed over; the rest of the caller's arrays stays untouched
+    const int32_t* hc = reinterpret_cast<const int32_t*>(c->pinOut);
+    for (int f = 0; f < nframes; f++) {
+        counts[f] = hc[f];
+        const size_t n = (size_t)std::min(std::max(hc[f], 0), cap);
+        std::memcpy(kps + (size_t)f * cap, c->pinOut + lay.kps + (size_t)f * cap * sizeof(orbx_keypoint),
+                    n * sizeof(orbx_keypoint));
+        std::memcpy(desc + (size_t)f * cap * ORBX_DESC_BYTES, c->pinOut + lay.desc + (size_t)f * cap * ORBX_DESC_BYTES,
+                    n * ORBX_DESC_BYTES);
+    }
     return ORBX_OK;
 }
 
