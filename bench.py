@@ -90,7 +90,7 @@ def cpu_baseline(seconds, frames):
     return {"value": round(all_core, 2), "unit": "frames/s", "cores": cores, "kind": "port",
             "single_core": round(single, 2),
             "sample": "%d distinct synthetic 752x480 frames, %d extractions in %.0f s on %d threads "
-                      "(oracle/liborb_oracle.so, g++ -O2)" % (len(frames), sum(done), seconds, cores)}
+                      "(oracle/liborb_oracle.so, g++ -O3)" % (len(frames), sum(done), seconds, cores)}
 
 
 def hamming_bench(torch, device):

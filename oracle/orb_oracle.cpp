@@ -8,7 +8,7 @@
  * from the published OpenCV 4.0.0 algorithms (imgproc resize.cpp / smooth.cpp, features2d
  * fast.cpp + fast_score.cpp, core mathfuncs_core) and marked "cv:".
  *
- * Build: g++ -O2 -ffp-contract=off (no FMA contraction: the x86 scalar build of OpenCV and of
+ * Build: g++ -O3 -ffp-contract=off (no FMA contraction: the x86 scalar build of OpenCV and of
  * the reference rounds every float product separately).
  */
 #include "orb_oracle.h"
