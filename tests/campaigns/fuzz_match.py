@@ -3,14 +3,14 @@
 UndistortKeyPoints + AssignFeaturesToGrid, SearchForInitialization, each against the CPU oracle with random
 sizes, settings, cameras and windows. Exits 1 with the failing case on the first difference.
 
-    python tools/fuzz_match.py [--cases 60] [--seed 1]
+    python tests/campaigns/fuzz_match.py [--cases 60] [--seed 1]
 """
 import argparse
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 

@@ -5,14 +5,14 @@ Every case builds a fresh context, extracts one frame (sometimes through an unal
 keypoint fields, angles (1e-3 deg) and descriptors. Prints the failing case's parameters and exits 1 on the
 first difference.
 
-    python tools/fuzz_parity.py [--cases 300] [--seed 1]
+    python tests/campaigns/fuzz_parity.py [--cases 300] [--seed 1]
 """
 import argparse
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 

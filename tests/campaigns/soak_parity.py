@@ -9,7 +9,7 @@
 Every keypoint field is compared exactly, angles within 1e-3 deg, descriptors bit for bit; stereo uRight /
 depth exactly. Prints one JSON object; exits 1 on any difference. The oracle runs on host threads.
 
-    python tools/soak_parity.py [--frames 4096] [--hd 64] [--stereo 128] [--threads 16]
+    python tests/campaigns/soak_parity.py [--frames 4096] [--hd 64] [--stereo 128] [--threads 16]
 """
 import argparse
 import json
@@ -18,7 +18,7 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
