@@ -182,6 +182,39 @@ def test_batch_equals_single_and_device_api():
         assert np.array_equal(gpu.get_level(1, frame=i, border=True), cpu.level_image(1, padded=True))
 
 
+def test_batch_with_padded_rows_and_gaps_between_frames():
+    """Host and device batch calls on views: row pitch and frame pitch larger than the image, odd base address."""
+    import ctypes as C
+    import torch
+    from my_orb_slam2_amd._lib import lib, np_ptr, check
+    B, W, H = 3, 751, 479
+    gpu, cpu = make(w=800, h=600, batch=4)
+    big = np.full((B, H + 4, 763), 200, np.uint8)
+    for i in range(B):
+        big[i, 2:2 + H, 5:5 + W] = m.synth_frame(40 + i, W, H)
+    view = big[:, 2:2 + H, 5:5 + W]
+    want = [cpu.extract(np.ascontiguousarray(view[i])) for i in range(B)]
+    cap = gpu.capacity
+    kps = np.empty((B, cap), m.KEYPOINT_DTYPE)
+    desc = np.empty((B, cap, 32), np.uint8)
+    cnt = np.zeros(B, np.int32)
+    check(lib().orbx_extract_batch(gpu._ctx, C.c_void_p(view.ctypes.data), B, W, H, view.strides[1], view.strides[0],
+                                   np_ptr(kps), np_ptr(desc), cap, np_ptr(cnt)), "orbx_extract_batch")
+    for i in range(B):
+        assert cnt[i] == len(want[i][0])
+        assert np.array_equal(kps[i, :cnt[i]]["x"], want[i][0]["x"]) and np.array_equal(desc[i, :cnt[i]], want[i][1])
+    d_big = torch.from_numpy(big).cuda()
+    d_view = d_big[:, 2:2 + H, 5:5 + W]
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    gpu.extract_batch_device(d_view, d_kps, d_desc, d_cnt)
+    gpu.synchronize()
+    assert np.array_equal(d_cnt.cpu().numpy(), cnt)
+    for i in range(B):
+        assert np.array_equal(d_desc[i, :cnt[i]].cpu().numpy(), want[i][1])
+
+
 def test_api_errors_and_empty_image():
     gpu, _ = make()
     k, d = gpu(np.empty((0, 0), np.uint8))
