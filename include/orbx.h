@@ -105,7 +105,9 @@ int orbx_extract(orbx_ctx* ctx, const uint8_t* image, int width, int height, siz
  * frame f starts at d_images + f*frame_stride. Outputs are device buffers: d_keypoints[f*cap ..],
  * d_descriptors[(f*cap ..)*32], d_counts[f] = keypoints found in frame f (only the first `cap` are
  * stored). Work is enqueued on `stream` (a hipStream_t; NULL = the context's own stream) and the
- * call returns without waiting. */
+ * call returns without waiting. Frames are read in place when d_images, row_stride and frame_stride are
+ * multiples of 4; otherwise the call first copies them into an aligned buffer of its own (one extra pass
+ * over the pixels), so tightly packed odd widths and views into larger images work, a little slower. */
 int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_images, int nframes, int width,
                               int height, size_t row_stride, size_t frame_stride,
                               orbx_keypoint* d_keypoints, uint8_t* d_descriptors, int cap,

@@ -21,9 +21,6 @@ namespace orbx {
 
 namespace {
 
-// floor(i / n) for 0 <= i < 65536/n, n >= 1 (multiply by a rounded-up reciprocal)
-__device__ __forceinline__ int div_small(int i, int recip) { return (int)(((unsigned)i * (unsigned)recip) >> 16); }
-
 // Corner strength of the pixel at p (LDS, row pitch `pitch`): see step 3 above.
 template <int pitch>
 __device__ __forceinline__ int corner_strength(const uint8_t* p) {
@@ -85,7 +82,7 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool ALIGNED4, int PITCH>
+template <int PITCH>
 __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSet fs, PyramidGeom g, int iniTh,
                                                                           int minTh, int ldsPerWave) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
@@ -131,7 +128,7 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     // Tile column c holds image column iniX - 1 + c, so the first scanned pixel (iniX + 3) sits at tile column 4
     // and groups of four scanned pixels are whole LDS dwords.
     constexpr int xo = 1;
-    if (ALIGNED4) {
+    {
         const int xa = (iniX - 1) & ~3;
         const uint32_t shift = (uint32_t)((iniX - 1) & 3);
         const int ndw = (maxX - iniX + 1 + 3) >> 2;
@@ -160,14 +157,6 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
                 for (int q = 0; q < kBatch; q++)
                     tile32[(r0 + kRowsPerStep * q) * (PITCH / 4)] = __builtin_amdgcn_alignbyte(hi[q], lo[q], shift);
             }
-        }
-    } else {
-        const int tw = maxX - iniX + 1;
-        const int recip = (65536 + tw - 1) / tw;
-        for (int i = lane; i < tw * th; i += 64) {
-            const int y = div_small(i, recip);
-            const int x = i - y * tw;
-            tile[y * pitch + x] = img[(long long)(iniY + y) * rowStride + iniX - 1 + x];
         }
     }
     uint8_t* score = smem + g.maxTileBytes;            // (sw+2) x (sh+2), zero ring
@@ -294,7 +283,8 @@ hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nfram
     const int ldsPerWave = (g.maxTileBytes + g.maxScoreBytes + 2 * g.maxScanPix + 16 + 15) & ~15;
     const size_t lds = (size_t)ldsPerWave * kCellsPerBlock;
     dim3 grid(nframes, (g.totalCells + kCellsPerBlock - 1) / kCellsPerBlock, 1), block(64 * kCellsPerBlock, 1, 1);
-    const bool aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
+    // level 0 is read with dword loads like the other levels: the caller of this launcher has made it 4-byte aligned
+    if ((uintptr_t)fs.img % 4 || fs.imgRowStride % 4 || fs.imgFrameStride % 4) return hipErrorInvalidValue;
     const bool small = g.tilePitch == 48;
     // the widest possible cells (59 x 59 px at pitch 80) need a little over the default 64 KB of dynamic LDS
     auto launch = [&](auto kernel) -> hipError_t {
@@ -306,10 +296,7 @@ hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nfram
         hipLaunchKernelGGL(kernel, grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
         return hipGetLastError();
     };
-    if (aligned && small) return launch(fast_cells_kernel<true, 48>);
-    if (aligned) return launch(fast_cells_kernel<true, 80>);
-    if (small) return launch(fast_cells_kernel<false, 48>);
-    return launch(fast_cells_kernel<false, 80>);
+    return small ? launch(fast_cells_kernel<48>) : launch(fast_cells_kernel<80>);
 }
 
 }  // namespace orbx

@@ -246,6 +246,24 @@ extern "C" int orbx_keypoint_capacity(const orbx_ctx* c) {
     return cap;
 }
 
+namespace {
+constexpr size_t kPinInMax = 16u << 20;   // host inputs up to this size are packed through pinned memory
+
+// Device staging for frames (max_batch frames of the largest size, 4-byte-multiple row pitch) and its small
+// pinned twin on the host.
+int ensure_stage_img(orbx_ctx* c) {
+    if (c->stageImg) return ORBX_OK;
+    const size_t all = (size_t)c->cfg.max_batch * (((size_t)c->cfg.max_width + 3) & ~(size_t)3) * c->cfg.max_height;
+    int rc = dev_alloc(&c->stageImg, all);
+    if (rc) return rc;
+    void* p = nullptr;
+    c->pinInBytes = std::min(all, kPinInMax);
+    HIP_TRY(hipHostMalloc(&p, c->pinInBytes, hipHostMallocDefault));
+    c->pinIn = static_cast<uint8_t*>(p);
+    return ORBX_OK;
+}
+}  // namespace
+
 extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, int nframes, int width,
                                          int height, size_t row_stride, size_t frame_stride,
                                          orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts,
@@ -264,6 +282,18 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, i
     if ((rc = ensure_geometry(c, width, height))) return rc;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     FrameSet fs = c->fs;
+    if (nframes == 1) frame_stride = 0;                 // never used to address anything
+    if ((uintptr_t)d_images % 4 || row_stride % 4 || frame_stride % 4) {
+        // The kernels read level 0 in place with dword loads: frames that are not 4-byte aligned (odd widths
+        // packed tightly, views into larger images) are first copied into the aligned staging layout.
+        if ((rc = ensure_stage_img(c))) return rc;
+        const size_t pitch = ((size_t)width + 3) & ~(size_t)3;
+        HIP_TRY(launch_repack_frames(d_images, (long long)row_stride, (long long)frame_stride, c->stageImg,
+                                     (long long)pitch, (long long)(pitch * (size_t)height), width, height, nframes, s));
+        d_images = c->stageImg;
+        row_stride = pitch;
+        frame_stride = pitch * (size_t)height;
+    }
     fs.img = d_images;
     fs.imgRowStride = (long long)row_stride;
     fs.imgFrameStride = (long long)frame_stride;
@@ -286,8 +316,6 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, i
 }
 
 namespace {
-constexpr size_t kPinInMax = 16u << 20;   // inputs up to this size are packed through pinned memory
-
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Offsets of the three outputs of one call inside the output block.
@@ -302,15 +330,8 @@ struct OutLayout {
 
 int ensure_staging(orbx_ctx* c, int cap) {
     const size_t B = (size_t)c->cfg.max_batch;
-    if (!c->stageImg) {
-        const size_t all = B * (((size_t)c->cfg.max_width + 3) & ~(size_t)3) * c->cfg.max_height;
-        int rc = dev_alloc(&c->stageImg, all);
-        if (rc) return rc;
-        void* p = nullptr;
-        c->pinInBytes = std::min(all, kPinInMax);
-        HIP_TRY(hipHostMalloc(&p, c->pinInBytes, hipHostMallocDefault));
-        c->pinIn = static_cast<uint8_t*>(p);
-    }
+    int rc = ensure_stage_img(c);
+    if (rc) return rc;
     if (cap > c->stageCap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->stageOut) HIP_TRY(hipFree(c->stageOut));
@@ -319,8 +340,7 @@ int ensure_staging(orbx_ctx* c, int cap) {
         c->pinOut = nullptr;
         c->stageCap = 0;
         const OutLayout lay(B, (size_t)cap);
-        int rc = dev_alloc(&c->stageOut, lay.total);
-        if (rc) return rc;
+        if ((rc = dev_alloc(&c->stageOut, lay.total))) return rc;
         void* p = nullptr;
         HIP_TRY(hipHostMalloc(&p, lay.total, hipHostMallocDefault));
         c->pinOut = static_cast<uint8_t*>(p);

@@ -123,6 +123,9 @@ struct PyramidView {
 void set_error(const char* fmt, ...);
 
 // ---- kernel launchers (one per .hip file) ----
+hipError_t launch_repack_frames(const uint8_t* src, long long srcRowStride, long long srcFrameStride, uint8_t* dst,
+                                long long dstRowStride, long long dstFrameStride, int w, int h, int nframes,
+                                hipStream_t s);
 hipError_t launch_pyramid(const FrameSet& fs, const PyramidGeom& g, const ResizeTab* tabs, int nframes,
                           hipStream_t s);
 hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nframes, int iniTh, int minTh,

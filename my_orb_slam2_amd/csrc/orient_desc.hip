@@ -248,7 +248,6 @@ __global__ __launch_bounds__(64) void sel_prefix_kernel(FrameSet fs, int nlevels
 
 // 22.5 KB of LDS per workgroup lets seven workgroups share a CU; seven waves per SIMD need <= 72 VGPRs, which is
 // why the pattern rows are fetched only after the row pass.
-template <bool ALIGNED4>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameSet fs, PyramidGeom g,
                                                                            int blurTaps,
                                                                            orbx_keypoint* __restrict__ kpsOut,
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     // Columns kx-21 .. kx+21 are used. When they all lie inside the level the rows come in as dwords: lane
     // (row slot, dword d) reads the two aligned dwords around its four bytes; dwords that stick out of the
     // row are clamped into it (they only hold unused columns). Rows outside the level are reflected.
-    if (kx - kPR >= 0 && kx + kPR < L.w && (ALIGNED4 || l > 0)) {
+    if (kx - kPR >= 0 && kx + kPR < L.w) {
         const int xa = (kx - kCx) & ~3;
         const uint32_t shift = (uint32_t)((kx - kCx) & 3);
         const int d = lane & 15, rs = lane >> 4;
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
                 R32[(rs + 4 * q) * 12 + d] = __builtin_amdgcn_alignbyte(hi[q], lo[q], shift);
         }
     } else {
-        // within two pixels of the level's left/right border, or unaligned caller memory: bytes,
+        // within two pixels of the level's left/right border: bytes,
         // BORDER_REFLECT_101 coordinates
         for (int i = lane; i < kRowsAlloc * kRPitch; i += 64) {
             const int r = i / kRPitch, c = i - r * kRPitch;
@@ -479,13 +478,11 @@ __global__ __launch_bounds__(256) void blur_level_kernel(const uint8_t* __restri
 
 hipError_t launch_orient_desc(const FrameSet& fs, const PyramidGeom& g, int nframes, int blurTaps,
                               orbx_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, hipStream_t s) {
+    // level 0 is read with dword loads like the other levels: the caller of this launcher has made it 4-byte aligned
+    if ((uintptr_t)fs.img % 4 || fs.imgRowStride % 4 || fs.imgFrameStride % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sel_prefix_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, fs, g.nlevels, nframes, counts);
     dim3 grid(nframes, (g.totalSel + kWavesPerBlock - 1) / kWavesPerBlock, 1), block(64 * kWavesPerBlock, 1, 1);
-    const bool aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
-    if (aligned)
-        hipLaunchKernelGGL(orient_desc_kernel<true>, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts);
-    else
-        hipLaunchKernelGGL(orient_desc_kernel<false>, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts);
+    hipLaunchKernelGGL(orient_desc_kernel, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts);
     return hipGetLastError();
 }
 

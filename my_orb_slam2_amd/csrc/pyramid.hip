@@ -47,10 +47,11 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restri
 
 // Fast path: same arithmetic, far fewer instructions. A thread makes four destination pixels per row for
 // kRowsPerThread consecutive rows; a wave (threadIdx.y) owns whole rows, so everything that depends only
-// on the row is scalar. Per source row: three aligned dword loads (the 12 bytes around the first source
-// column), two v_alignbyte to bring that column to byte 0 of an 8-byte window, and per pixel one
-// v_perm_b32 that puts S[sx], S[sx+1] into the two 16-bit halves plus one v_dot2_i32_i16 with the
-// packed weights (a0, a1). Consecutive destination rows share a source row most of the time (the lower
+// on the row is scalar. Per source row: three dword loads through a buffer resource (the 12 bytes around the
+// first source column: scalar row offset + per-lane constant offsets), two v_alignbyte to bring that column to
+// byte 0 of an 8-byte window, and per pixel one v_perm_b32 that puts S[sx], S[sx+1] into the two 16-bit halves
+// plus one v_dot2_u32_u16 with the packed weights (a0, a1). The vertical pass is two v_mul_hi_u32 per pixel with
+// the row weights pre-shifted by 16. Consecutive destination rows share a source row most of the time (the lower
 // row of one is the upper row of the next); its horizontal sums are kept in registers. The per-column
 // table record is 8 bytes, {sx for the first column of a group of four, else the v_perm selector;
 // a0 | a1 << 16}, built on the host and loaded once per thread. Needs 4-byte aligned rows and a
@@ -139,6 +140,29 @@ __global__ __launch_bounds__(256) void pyr_resize_dword_kernel(const uint8_t* __
         cachedSy = sy1;
         vrow(dy, bb, ha, hb);
     }
+}
+
+// Copies frames of any base address and strides into the 4-byte-aligned layout every other kernel's fast path
+// wants (dword loads): one thread moves four pixels. Bytes past the row's end repeat its last pixel.
+__global__ __launch_bounds__(256) void repack_frames_kernel(const uint8_t* __restrict__ src, long long srcRowStride,
+                                                            long long srcFrameStride, uint8_t* __restrict__ dst,
+                                                            long long dstRowStride, long long dstFrameStride, int w) {
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x4 >= w) return;
+    const uint8_t* S = src + (long long)blockIdx.z * srcFrameStride + (long long)blockIdx.y * srcRowStride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (uint32_t)S[min(x4 + k, w - 1)] << (8 * k);
+    *reinterpret_cast<uint32_t*>(dst + (long long)blockIdx.z * dstFrameStride + (long long)blockIdx.y * dstRowStride + x4) = v;
+}
+
+hipError_t launch_repack_frames(const uint8_t* src, long long srcRowStride, long long srcFrameStride, uint8_t* dst,
+                                long long dstRowStride, long long dstFrameStride, int w, int h, int nframes,
+                                hipStream_t s) {
+    dim3 grid((w + 1023) / 1024, h, nframes), block(256, 1, 1);
+    hipLaunchKernelGGL(repack_frames_kernel, grid, block, 0, s, src, srcRowStride, srcFrameStride, dst, dstRowStride,
+                       dstFrameStride, w);
+    return hipGetLastError();
 }
 
 hipError_t launch_pyramid(const FrameSet& fs, const PyramidGeom& g, const ResizeTab* tabs, int nframes,
