@@ -182,6 +182,15 @@ def test_batch_equals_single_and_device_api():
         assert np.array_equal(gpu.get_level(1, frame=i, border=True), cpu.level_image(1, padded=True))
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (16, 16), (38, 38), (39, 50), (62, 62), (80, 45), (45, 80)])
+def test_images_smaller_than_borders_and_cells(w, h):
+    """Levels too small for the 16-px border or one 30-px cell yield nothing (the reference divides by a zero cell
+    count there, src/ORBextractor.cc:776-779); whatever still fits must match the oracle."""
+    gpu, cpu = make(nfeatures=300, w=80, h=80)
+    img = np.random.default_rng(w * 100 + h).integers(0, 256, (h, w), dtype=np.uint8)
+    compare_frame(gpu, cpu, img, stages=False)
+
+
 def test_batch_with_padded_rows_and_gaps_between_frames():
     """Host and device batch calls on views: row pitch and frame pitch larger than the image, odd base address."""
     import ctypes as C
