@@ -960,6 +960,16 @@ extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint
         if (!(fv1_nodes[j] < fv1_nodes[j + 1])) { set_error("orbx_search_by_bow: fv1_nodes not ascending"); return ORBX_ERR_INVALID; }
     for (int j = 0; j + 1 < fv2_n; j++)
         if (!(fv2_nodes[j] < fv2_nodes[j + 1])) { set_error("orbx_search_by_bow: fv2_nodes not ascending"); return ORBX_ERR_INVALID; }
+    for (int side = 0; side < 2; side++) {
+        const int32_t* st = side ? fv2_start : fv1_start;
+        const int n = side ? fv2_n : fv1_n;
+        bool ok = n == 0 || st[0] == 0;
+        for (int j = 0; ok && j < n; j++) ok = st[j] <= st[j + 1];
+        if (!ok) {
+            set_error("orbx_search_by_bow: fv%d_start must rise from 0", side + 1);
+            return ORBX_ERR_INVALID;
+        }
+    }
     *nmatches = 0;
     const int nout = kfkf ? n1 : n2;
     for (int i = 0; i < nout; i++) matches[i] = -1;
@@ -1015,6 +1025,22 @@ extern "C" int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoi
     hipStream_t s = m->stream;
     const int kCells = ORBX_GRID_COLS * ORBX_GRID_ROWS;
     const int nItems = cell_start2[kCells];
+    {
+        // The kernel follows these indices: a grid that is not a partition of (a subset of) frame 2's keypoints
+        // is refused here rather than read out of bounds there.
+        bool ok = cell_start2[0] == 0 && nItems >= 0 && nItems <= n2;
+        for (int c = 0; ok && c < kCells; c++) ok = cell_start2[c] <= cell_start2[c + 1];
+        std::vector<uint8_t> seen(ok ? (size_t)n2 : 0, 0);
+        for (int j = 0; ok && j < nItems; j++) {
+            const int32_t i2 = cell_items2[j];
+            ok = i2 >= 0 && i2 < n2 && !seen[i2];
+            if (ok) seen[i2] = 1;
+        }
+        if (!ok) {
+            set_error("orbx_search_for_initialization: cell_start2 / cell_items2 do not describe a grid of frame 2");
+            return ORBX_ERR_INVALID;
+        }
+    }
     int maxCand = 0;                              // a query can meet every level-0 keypoint of frame 2 at most
     for (int i = 0; i < n2; i++) maxCand += keys2_un[i].octave == 0;
     maxCand = std::max(maxCand, 1);

@@ -89,3 +89,25 @@ def test_search_for_initialization():
     n, got = hm.search_for_initialization(k1, d1, k2[:0], d2[:0], np.zeros(64 * 48 + 1, np.int32), np.zeros(1, np.int32),
                                           bounds, prev)
     assert n == 0 and np.all(got == -1)
+
+
+def test_search_for_initialization_refuses_a_malformed_grid():
+    """Indices the kernel would follow are checked on the host: out of range, repeated, starts that fall."""
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    ex = m.ORBextractor(500, 1.2, 8, 20, 7)
+    hm = m.HammingMatcher()
+    k1, d1 = ex(m.synth_frame(82))
+    k2, d2 = ex(m.synth_frame(82, right_view=True))
+    start, items = orc.assign_grid(k2, bounds)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32).copy()
+    n_ok, _ = hm.search_for_initialization(k1, d1, k2, d2, start, items, bounds, prev.copy())
+    assert n_ok > 0
+    bad_items = items.copy()
+    bad_items[3] = len(k2) + 7
+    bad_dup = items.copy()
+    bad_dup[5] = bad_dup[4]
+    bad_start = start.copy()
+    bad_start[100] = bad_start[99] - 1 if bad_start[99] > 0 else -1
+    for s, it in ((start, bad_items), (start, bad_dup), (bad_start, items)):
+        with pytest.raises(m.OrbxError):
+            hm.search_for_initialization(k1, d1, k2, d2, s, it, bounds, prev.copy())

@@ -90,3 +90,8 @@ def test_search_by_bow_edges():
         hm.search_by_bow(k1, d1, v1, fv1, k2, d2, bad)
     with pytest.raises(m.OrbxError):
         hm.search_by_bow(k1, d1, v1, (fv1[0][::-1].copy(), fv1[1], fv1[2]), k2, d2, fv2)
+    # start offsets that fall are rejected before anything is indexed with them
+    bad_start = fv2[1].copy()
+    bad_start[2] = bad_start[1] - 1 if bad_start[1] > 0 else -1
+    with pytest.raises(m.OrbxError):
+        hm.search_by_bow(k1, d1, v1, fv1, k2, d2, (fv2[0], bad_start, fv2[2]))
