@@ -641,6 +641,8 @@ struct orbx_matcher {
     hipStream_t stream = nullptr;
     void* scratch = nullptr;
     size_t scratchBytes = 0;
+    uint8_t* pin = nullptr;   // pinned host staging of the host-array entry points: one copy in, one copy out
+    size_t pinBytes = 0;
     float* scale = nullptr;   // device copy of scale factors [0..15] and inverse scale factors [16..31]
     float hostScale[2 * ORBX_MAX_LEVELS] = {0};   // what `scale` holds
     bool scaleValid = false;
@@ -658,6 +660,21 @@ int matcher_scratch(orbx_matcher* m, size_t bytes, hipStream_t s) {
     m->scratchBytes = 0;
     HIP_TRY(hipMalloc(&m->scratch, bytes));
     m->scratchBytes = bytes;
+    return ORBX_OK;
+}
+
+// Grows the pinned staging buffer (contents are lost).
+int matcher_pinned(orbx_matcher* m, size_t bytes) {
+    if (bytes <= m->pinBytes) return ORBX_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->pin) HIP_TRY(hipHostFree(m->pin));
+    m->pin = nullptr;
+    m->pinBytes = 0;
+    bytes += bytes / 2;
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    m->pin = static_cast<uint8_t*>(p);
+    m->pinBytes = bytes;
     return ORBX_OK;
 }
 }  // namespace
@@ -686,6 +703,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher* m) {
     if (!m) return;
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->scratch) (void)hipFree(m->scratch);
+    if (m->pin) (void)hipHostFree(m->pin);
     if (m->scale) (void)hipFree(m->scale);
     for (hipEvent_t ev : {m->evIn[0], m->evIn[1], m->evOut})
         if (ev) (void)hipEventDestroy(ev);
@@ -985,23 +1003,26 @@ extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint
     hipStream_t s = m->stream;
     const int nItems2 = fv2_start[fv2_n];
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    // inputs packed in pinned memory in the layout of the device scratch: one copy in, one copy out
     const size_t oD1 = 0, oD2 = oD1 + up(32 * (size_t)n1), oIt = oD2 + up(32 * (size_t)n2),
                  oRw = oIt + up(4 * (size_t)nItems2), oDs = oRw + up(sizeof(BowRow) * rows.size()),
                  total = oDs + up(2 * (size_t)npairs);
     int rc = matcher_scratch(m, total, s);
     if (rc) return rc;
+    if ((rc = matcher_pinned(m, total))) return rc;
     uint8_t* base = static_cast<uint8_t*>(m->scratch);
-    HIP_TRY(hipMemcpyAsync(base + oD1, desc1, 32 * (size_t)n1, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(base + oD2, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(base + oIt, fv2_items, 4 * (size_t)nItems2, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(base + oRw, rows.data(), sizeof(BowRow) * rows.size(), hipMemcpyHostToDevice, s));
+    std::memcpy(m->pin + oD1, desc1, 32 * (size_t)n1);
+    std::memcpy(m->pin + oD2, desc2, 32 * (size_t)n2);
+    std::memcpy(m->pin + oIt, fv2_items, 4 * (size_t)nItems2);
+    std::memcpy(m->pin + oRw, rows.data(), sizeof(BowRow) * rows.size());
+    HIP_TRY(hipMemcpyAsync(base, m->pin, oDs, hipMemcpyHostToDevice, s));
     HIP_TRY(launch_bow_distances((int)rows.size(), reinterpret_cast<const BowRow*>(base + oRw), base + oD1,
                                  reinterpret_cast<const uint32_t*>(base + oIt), base + oD2,
                                  reinterpret_cast<uint16_t*>(base + oDs), s));
-    std::vector<uint16_t> dist((size_t)npairs);
-    HIP_TRY(hipMemcpyAsync(dist.data(), base + oDs, 2 * (size_t)npairs, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(m->pin + oDs, base + oDs, 2 * (size_t)npairs, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *nmatches = replay_search_by_bow(mode, rows, dist.data(), fv2_items, keys1_un, keys2, valid2, n1, n2, nnratio,
+    const uint16_t* dist = reinterpret_cast<const uint16_t*>(m->pin + oDs);
+    *nmatches = replay_search_by_bow(mode, rows, dist, fv2_items, keys1_un, keys2, valid2, n1, n2, nnratio,
                                      check_orientation != 0, matches);
     return ORBX_OK;
 }
@@ -1041,40 +1062,62 @@ extern "C" int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoi
             return ORBX_ERR_INVALID;
         }
     }
-    int maxCand = 0;                              // a query can meet every level-0 keypoint of frame 2 at most
-    for (int i = 0; i < n2; i++) maxCand += keys2_un[i].octave == 0;
-    maxCand = std::max(maxCand, 1);
+    // a level-0 query can meet every level-0 keypoint of frame 2 at most: the bound of the packed candidate list
+    long long q0 = 0, t0 = 0;
+    for (int i = 0; i < n1; i++) q0 += keys1_un[i].octave <= 0;
+    for (int i = 0; i < n2; i++) t0 += keys2_un[i].octave == 0;
+    if (n2 > 0x7FFFFF || q0 * t0 > 0x3FFFFFFF) {
+        set_error("orbx_search_for_initialization: too many keypoints (%d x %d)", n1, n2);
+        return ORBX_ERR_INVALID;
+    }
+    const int capTotal = (int)std::max(q0 * t0, 1LL);
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    // inputs packed in pinned memory in the layout of the device scratch: one copy in
     const size_t oK1 = 0, oD1 = oK1 + up(sizeof(orbx_keypoint) * n1), oK2 = oD1 + up(32 * (size_t)n1),
                  oD2 = oK2 + up(sizeof(orbx_keypoint) * n2), oCs = oD2 + up(32 * (size_t)n2),
                  oCi = oCs + up(4 * (size_t)(kCells + 1)), oPv = oCi + up(4 * (size_t)std::max(nItems, 1)),
-                 oCc = oPv + up(8 * (size_t)n1), oIx = oCc + up(4 * (size_t)n1),
-                 oDs = oIx + up(4 * (size_t)n1 * maxCand), total = oDs + up(4 * (size_t)n1 * maxCand);
+                 oHd = oPv + up(8 * (size_t)n1),                      // results: cursor, counts, offsets
+                 oCd = oHd + up(4 * (1 + 2 * (size_t)n1)), total = oCd + up(4 * (size_t)capTotal);
     int rc = matcher_scratch(m, total, s);
     if (rc) return rc;
+    if ((rc = matcher_pinned(m, oCd))) return rc;
     uint8_t* base = static_cast<uint8_t*>(m->scratch);
-    HIP_TRY(hipMemcpyAsync(base + oK1, keys1_un, sizeof(orbx_keypoint) * n1, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(base + oD1, desc1, 32 * (size_t)n1, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(base + oK2, keys2_un, sizeof(orbx_keypoint) * n2, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(base + oD2, desc2, 32 * (size_t)n2, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(base + oCs, cell_start2, 4 * (size_t)(kCells + 1), hipMemcpyHostToDevice, s));
-    if (nItems > 0) HIP_TRY(hipMemcpyAsync(base + oCi, cell_items2, 4 * (size_t)nItems, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(base + oPv, prev_matched, 8 * (size_t)n1, hipMemcpyHostToDevice, s));
+    std::memcpy(m->pin + oK1, keys1_un, sizeof(orbx_keypoint) * n1);
+    std::memcpy(m->pin + oD1, desc1, 32 * (size_t)n1);
+    std::memcpy(m->pin + oK2, keys2_un, sizeof(orbx_keypoint) * n2);
+    std::memcpy(m->pin + oD2, desc2, 32 * (size_t)n2);
+    std::memcpy(m->pin + oCs, cell_start2, 4 * (size_t)(kCells + 1));
+    if (nItems > 0) std::memcpy(m->pin + oCi, cell_items2, 4 * (size_t)nItems);
+    std::memcpy(m->pin + oPv, prev_matched, 8 * (size_t)n1);
+    HIP_TRY(hipMemcpyAsync(base, m->pin, oHd, hipMemcpyHostToDevice, s));
     const float invW = static_cast<float>(ORBX_GRID_COLS) / (max_x - min_x);
     const float invH = static_cast<float>(ORBX_GRID_ROWS) / (max_y - min_y);
+    int32_t* hd = reinterpret_cast<int32_t*>(base + oHd);
     HIP_TRY(launch_window_candidates(n1, reinterpret_cast<const orbx_keypoint*>(base + oK1), base + oD1,
                                      reinterpret_cast<const orbx_keypoint*>(base + oK2), base + oD2,
                                      reinterpret_cast<const int32_t*>(base + oCs),
                                      reinterpret_cast<const int32_t*>(base + oCi),
                                      reinterpret_cast<const float*>(base + oPv), min_x, min_y, invW, invH,
-                                     (float)window_size, maxCand, reinterpret_cast<int32_t*>(base + oCc),
-                                     reinterpret_cast<int32_t*>(base + oIx), reinterpret_cast<int32_t*>(base + oDs), s));
-    std::vector<int32_t> cc(n1), ci((size_t)n1 * maxCand), cd((size_t)n1 * maxCand);
-    HIP_TRY(hipMemcpyAsync(cc.data(), base + oCc, 4 * (size_t)n1, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(ci.data(), base + oIx, 4 * (size_t)n1 * maxCand, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(cd.data(), base + oDs, 4 * (size_t)n1 * maxCand, hipMemcpyDeviceToHost, s));
+                                     (float)window_size, capTotal, hd, hd + 1, hd + 1 + n1,
+                                     reinterpret_cast<uint32_t*>(base + oCd), s));
+    HIP_TRY(hipMemcpyAsync(m->pin + oHd, base + oHd, 4 * (1 + 2 * (size_t)n1), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    *nmatches = replay_search_for_initialization(keys1_un, n1, keys2_un, n2, cc.data(), ci.data(), cd.data(), maxCand,
-                                                 prev_matched, nnratio, check_orientation != 0, matches12);
+    // the header leaves the pinned buffer before the buffer may grow for the candidate list
+    std::vector<int32_t> head(1 + 2 * (size_t)n1);
+    std::memcpy(head.data(), m->pin + oHd, 4 * head.size());
+    const size_t ncand = (size_t)std::min(std::max(head[0], 0), capTotal);
+    if ((rc = matcher_pinned(m, std::max<size_t>(4 * ncand, 4)))) return rc;
+    if (ncand > 0) {
+        HIP_TRY(hipMemcpyAsync(m->pin, base + oCd, 4 * ncand, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    for (int i = 0; i < n1; i++)                      // a list must lie inside what was copied
+        if (head[1 + i] < 0 || head[1 + n1 + i] < 0 || (size_t)head[1 + n1 + i] + (size_t)head[1 + i] > ncand) {
+            set_error("orbx_search_for_initialization: inconsistent candidate lists");
+            return ORBX_ERR_STATE;
+        }
+    *nmatches = replay_search_for_initialization(keys1_un, n1, keys2_un, n2, head.data() + 1, head.data() + 1 + n1,
+                                                 reinterpret_cast<const uint32_t*>(m->pin), prev_matched, nnratio,
+                                                 check_orientation != 0, matches12);
     return ORBX_OK;
 }

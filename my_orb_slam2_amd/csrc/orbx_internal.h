@@ -177,11 +177,11 @@ int replay_search_by_bow(int mode, const std::vector<BowRow>& rows, const uint16
 hipError_t launch_window_candidates(int n1, const orbx_keypoint* k1, const uint8_t* d1, const orbx_keypoint* k2,
                                     const uint8_t* d2, const int32_t* cellStart, const int32_t* cellItems,
                                     const float* prev, float minX, float minY, float invW, float invH, float r,
-                                    int maxCand, int32_t* candCount, int32_t* candIdx, int32_t* candDist,
-                                    hipStream_t s);
+                                    int capTotal, int32_t* cursor, int32_t* candCount, int32_t* candOffset,
+                                    uint32_t* cand, hipStream_t s);
 int replay_search_for_initialization(const orbx_keypoint* k1, int n1, const orbx_keypoint* k2, int n2,
-                                     const int32_t* candCount, const int32_t* candIdx, const int32_t* candDist,
-                                     int maxCand, float* prev, float nnratio, bool checkOri, int32_t* matches12);
+                                     const int32_t* candCount, const int32_t* candOffset, const uint32_t* cand,
+                                     float* prev, float nnratio, bool checkOri, int32_t* matches12);
 void undistort_point_host(const orbx_camera& cam, float u, float v, float* xo, float* yo);
 
 }  // namespace orbx

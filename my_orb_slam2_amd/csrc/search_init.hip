@@ -1,9 +1,9 @@
 // ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:413-530).
 //
 // The data-parallel part — Frame::GetFeaturesInArea (src/Frame.cc:365-418) for every level-0 keypoint of
-// frame 1 and ORBmatcher::DescriptorDistance (:1698-1714) to every candidate — runs on the GPU, one thread
+// frame 1 and ORBmatcher::DescriptorDistance (:1698-1714) to every candidate — runs on the GPU, one wave
 // per frame-1 keypoint, and leaves per-keypoint candidate lists (index, distance) in the order the
-// reference visits them. The rest of the function depends on the order in which frame-1 keypoints are
+// reference visits them, packed one after the other. The rest of the function depends on the order in which frame-1 keypoints are
 // processed (vMatchedDistance, vnMatches21), so it is replayed on the host over those lists.
 #include <cmath>
 #include <vector>
@@ -16,6 +16,14 @@ struct GridParams {
     float minX, minY, invW, invH;
 };
 
+// A candidate is one word: distance << 23 | index in frame 2. A query's candidates are contiguous at
+// cand[candOffset[i1] ..) in visiting order; the regions are handed out by an atomic cursor after a counting pass,
+// so the list is as long as the candidates that exist and not n1 x (largest possible list).
+//
+// One wave per frame-1 keypoint. The window's cells, numbered in the reference's visiting order (columns outside,
+// rows inside, :387-410), are taken 64 at a time, one cell per lane, so the dependent loads of a cell (its start,
+// its keypoint indices, their positions) run side by side for 64 cells; a prefix sum over the lanes' counts puts
+// every cell's candidates where the sequential walk would have put them.
 __global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const orbx_keypoint* __restrict__ k1,
                                                                 const uint4* __restrict__ d1,
                                                                 const orbx_keypoint* __restrict__ k2,
@@ -23,12 +31,14 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const or
                                                                 const int32_t* __restrict__ cellStart,
                                                                 const int32_t* __restrict__ cellItems,
                                                                 const float* __restrict__ prev, GridParams gp, float r,
-                                                                int maxCand, int32_t* __restrict__ candCount,
-                                                                int32_t* __restrict__ candIdx,
-                                                                int32_t* __restrict__ candDist) {
-    const int i1 = blockIdx.x * 256 + threadIdx.x;
+                                                                int capTotal, int32_t* __restrict__ cursor,
+                                                                int32_t* __restrict__ candCount,
+                                                                int32_t* __restrict__ candOffset,
+                                                                uint32_t* __restrict__ cand) {
+    const int lane = threadIdx.x & 63;
+    const int i1 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (i1 >= n1) return;
-    int count = 0;
+    int total = 0, offset = 0;
     if (k1[i1].octave <= 0) {                                  // level1 > 0: continue (:429-431)
         const float x = prev[2 * i1], y = prev[2 * i1 + 1];
         // GetFeaturesInArea(x, y, r, 0, 0)
@@ -36,31 +46,72 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const or
         const int nMaxCellX = min(ORBX_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, gp.minX), r), gp.invW)));
         const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, gp.minY), r), gp.invH)));
         const int nMaxCellY = min(ORBX_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, gp.minY), r), gp.invH)));
-        if (!(nMinCellX >= ORBX_GRID_COLS || nMaxCellX < 0 || nMinCellY >= ORBX_GRID_ROWS || nMaxCellY < 0)) {
-            const uint4 qa = d1[2 * i1], qb = d1[2 * i1 + 1];
-            for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
-                for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
-                    const int c = ix * ORBX_GRID_ROWS + iy;
-                    for (int j = cellStart[c]; j < cellStart[c + 1]; j++) {
-                        const int i2 = cellItems[j];
-                        const orbx_keypoint kp = k2[i2];
-                        if (kp.octave < 0 || kp.octave > 0) continue;          // minLevel = maxLevel = 0
-                        const float distx = __fsub_rn(kp.x, x), disty = __fsub_rn(kp.y, y);
-                        if (!(fabsf(distx) < r && fabsf(disty) < r)) continue;
-                        const uint4 ra = d2[2 * i2], rb = d2[2 * i2 + 1];
-                        const int dist = __popc(qa.x ^ ra.x) + __popc(qa.y ^ ra.y) + __popc(qa.z ^ ra.z) +
-                                         __popc(qa.w ^ ra.w) + __popc(qb.x ^ rb.x) + __popc(qb.y ^ rb.y) +
-                                         __popc(qb.z ^ rb.z) + __popc(qb.w ^ rb.w);
-                        if (count < maxCand) {
-                            candIdx[(long long)i1 * maxCand + count] = i2;
-                            candDist[(long long)i1 * maxCand + count] = dist;
-                        }
-                        count++;
-                    }
+        if (!(nMinCellX >= ORBX_GRID_COLS || nMaxCellX < 0 || nMinCellY >= ORBX_GRID_ROWS || nMaxCellY < 0) &&
+            nMaxCellX >= nMinCellX && nMaxCellY >= nMinCellY) {
+            const int rows = nMaxCellY - nMinCellY + 1, ncells = (nMaxCellX - nMinCellX + 1) * rows;
+            // this lane's cell of a chunk: [begin, end) in cellItems, empty past the window
+            auto cell_range = [&](int chunk, int& jb, int& je) {
+                const int w = chunk + lane;
+                jb = je = 0;
+                if (w < ncells) {
+                    const int cx = w / rows, c = (nMinCellX + cx) * ORBX_GRID_ROWS + nMinCellY + (w - cx * rows);
+                    jb = cellStart[c];
+                    je = cellStart[c + 1];
                 }
+            };
+            auto passes = [&](int i2) {
+                const orbx_keypoint kp = k2[i2];
+                if (kp.octave < 0 || kp.octave > 0) return false;                  // minLevel = maxLevel = 0
+                const float distx = __fsub_rn(kp.x, x), disty = __fsub_rn(kp.y, y);
+                return fabsf(distx) < r && fabsf(disty) < r;
+            };
+            auto wave_incl_scan = [&](int v) {
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int u = __shfl_up(v, off);
+                    if (lane >= off) v += u;
+                }
+                return v;
+            };
+            for (int chunk = 0; chunk < ncells; chunk += 64) {
+                int jb, je, cnt = 0;
+                cell_range(chunk, jb, je);
+                for (int j = jb; j < je; j++) cnt += passes(cellItems[j]);
+                total += __builtin_amdgcn_readlane(wave_incl_scan(cnt), 63);
+            }
+            if (total > 0) {
+                if (lane == 0) offset = atomicAdd(cursor, total);
+                offset = __builtin_amdgcn_readfirstlane(offset);
+                if (offset + total <= capTotal) {          // always true for a grid that lists a keypoint once
+                    const uint4 qa = d1[2 * i1], qb = d1[2 * i1 + 1];
+                    int done = offset;
+                    for (int chunk = 0; chunk < ncells; chunk += 64) {
+                        int jb, je, cnt = 0;
+                        cell_range(chunk, jb, je);
+                        for (int j = jb; j < je; j++) cnt += passes(cellItems[j]);
+                        const int incl = wave_incl_scan(cnt);
+                        int k = done + incl - cnt;
+                        for (int j = jb; j < je; j++) {
+                            const int i2 = cellItems[j];
+                            if (!passes(i2)) continue;
+                            const uint4 ra = d2[2 * i2], rb = d2[2 * i2 + 1];
+                            const int dist = __popc(qa.x ^ ra.x) + __popc(qa.y ^ ra.y) + __popc(qa.z ^ ra.z) +
+                                             __popc(qa.w ^ ra.w) + __popc(qb.x ^ rb.x) + __popc(qb.y ^ rb.y) +
+                                             __popc(qb.z ^ rb.z) + __popc(qb.w ^ rb.w);
+                            cand[k++] = ((uint32_t)dist << 23) | (uint32_t)i2;
+                        }
+                        done += __builtin_amdgcn_readlane(incl, 63);
+                    }
+                } else {
+                    total = 0;
+                }
+            }
         }
     }
-    candCount[i1] = count;
+    if (lane == 0) {
+        candCount[i1] = total;
+        candOffset[i1] = offset;
+    }
 }
 
 namespace {
@@ -91,8 +142,8 @@ void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, in
 
 // Host half: src/ORBmatcher.cc:416-529 over the GPU-made candidate lists.
 int replay_search_for_initialization(const orbx_keypoint* k1, int n1, const orbx_keypoint* k2, int n2,
-                                     const int32_t* candCount, const int32_t* candIdx, const int32_t* candDist,
-                                     int maxCand, float* prev, float nnratio, bool checkOri, int32_t* matches12) {
+                                     const int32_t* candCount, const int32_t* candOffset, const uint32_t* cand,
+                                     float* prev, float nnratio, bool checkOri, int32_t* matches12) {
     const int HISTO_LENGTH = 30, TH_LOW = 50;   // include/PresetParameters.h:11-13
     int nmatches = 0;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
@@ -103,8 +154,9 @@ int replay_search_for_initialization(const orbx_keypoint* k1, int n1, const orbx
         const int nc = candCount[i1];
         if (nc == 0) continue;
         int bestDist = INT32_MAX, bestDist2 = INT32_MAX, bestIdx2 = -1;
+        const uint32_t* list = cand + candOffset[i1];
         for (int c = 0; c < nc; c++) {
-            const int i2 = candIdx[(size_t)i1 * maxCand + c], dist = candDist[(size_t)i1 * maxCand + c];
+            const int i2 = (int)(list[c] & 0x7FFFFFu), dist = (int)(list[c] >> 23);
             if (vMatchedDistance[i2] <= dist) continue;
             if (dist < bestDist) {
                 bestDist2 = bestDist;
@@ -157,13 +209,15 @@ int replay_search_for_initialization(const orbx_keypoint* k1, int n1, const orbx
 hipError_t launch_window_candidates(int n1, const orbx_keypoint* k1, const uint8_t* d1, const orbx_keypoint* k2,
                                     const uint8_t* d2, const int32_t* cellStart, const int32_t* cellItems,
                                     const float* prev, float minX, float minY, float invW, float invH, float r,
-                                    int maxCand, int32_t* candCount, int32_t* candIdx, int32_t* candDist,
-                                    hipStream_t s) {
+                                    int capTotal, int32_t* cursor, int32_t* candCount, int32_t* candOffset,
+                                    uint32_t* cand, hipStream_t s) {
     if (n1 <= 0) return hipSuccess;
     GridParams gp{minX, minY, invW, invH};
-    hipLaunchKernelGGL(window_candidates_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, n1, k1,
+    hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(window_candidates_kernel, dim3((n1 + 3) / 4), dim3(256), 0, s, n1, k1,
                        reinterpret_cast<const uint4*>(d1), k2, reinterpret_cast<const uint4*>(d2), cellStart,
-                       cellItems, prev, gp, r, maxCand, candCount, candIdx, candDist);
+                       cellItems, prev, gp, r, capTotal, cursor, candCount, candOffset, cand);
     return hipGetLastError();
 }
 

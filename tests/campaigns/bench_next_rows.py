@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Timing of the steps either side of extraction, the GPU path beside the CPU oracle on the same inputs:
+
+  undistort + grid      Frame::UndistortKeyPoints + AssignFeaturesToGrid, 256 frames of ~1000 keypoints, on the device
+  SearchForInitialization   two 2000-keypoint frames (the initialisation extractor), host arrays in and out
+  SearchByBoW           both overloads, 1000 x 1200 features over 120 vocabulary nodes and 2000 x 2000 over 40,
+                        host arrays in and out
+
+    python tests/campaigns/bench_next_rows.py
+
+One JSON object per step. The oracle is single-threaded, as the reference runs these on the tracking thread.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+
+def best_of(fn, reps, inner=1):
+    best = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(inner):
+            fn()
+        best = min(best, (time.perf_counter() - t0) / inner)
+    return best
+
+
+def main():
+    import torch
+    import my_orb_slam2_amd as m
+    from tests import oracle as orc
+    from tests.test_gpu_frame_grid import EUROC
+    from tests.test_gpu_search_bow import make_case
+
+    # ---- undistort + grid ----
+    B = 256
+    ex = m.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+    cap = ex.capacity
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(torch.from_numpy(m.synth_batch(0, B)).cuda(), d_kps, d_desc, d_cnt)
+    ex.synchronize()
+    hm = m.HammingMatcher()
+    cam = m.Camera(**EUROC)
+    bounds = hm.image_bounds(cam, 752, 480)
+    d_un = torch.zeros_like(d_kps)
+    d_start = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    d_items = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+
+    def gpu_grid():
+        hm.undistort_assign_grid_device(d_kps, d_cnt, cam, bounds, d_un, d_start, d_items)
+        hm.synchronize()
+    gpu_grid()
+    t_gpu = best_of(gpu_grid, 5, 4)
+    cnt = d_cnt.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(np.uint8).reshape(B, cap, 28).copy().view(m.KEYPOINT_DTYPE).reshape(B, cap)
+    K4 = [EUROC[k] for k in ("fx", "fy", "cx", "cy")]
+    D5 = [EUROC[k] for k in ("k1", "k2", "p1", "p2", "k3")]
+
+    def cpu_grid():
+        for f in range(16):
+            k = kps[f, :cnt[f]].copy()
+            xy = orc.undistort_points(np.stack([k["x"], k["y"]], 1), K4, D5)
+            k["x"], k["y"] = xy[:, 0], xy[:, 1]
+            orc.assign_grid(k, bounds)
+    t_cpu = best_of(cpu_grid, 3) / 16
+    print(json.dumps({"step": "undistort + grid", "frames": B, "mean_keypoints": float(cnt.mean()),
+                      "gpu_us_per_frame": round(t_gpu / B * 1e6, 3), "gpu_frames_per_s": round(B / t_gpu),
+                      "cpu_port_us_per_frame": round(t_cpu * 1e6, 1), "cpu_cores": 1}))
+
+    # ---- SearchForInitialization ----
+    ex2 = m.ORBextractor(2000, 1.2, 8, 20, 7)
+    k1, d1 = ex2(m.synth_frame(80))
+    k2, d2 = ex2(m.synth_frame(80, right_view=True))
+    b0 = (0.0, 0.0, 752.0, 480.0)
+    start, items = orc.assign_grid(k2, b0)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    n_gpu, _ = hm.search_for_initialization(k1, d1, k2, d2, start, items, b0, prev.copy())
+    t_gpu = best_of(lambda: hm.search_for_initialization(k1, d1, k2, d2, start, items, b0, prev.copy()), 5, 4)
+    t_cpu = best_of(lambda: orc.search_for_initialization(k1, d1, k2, d2, b0, prev.copy(), 100, 0.9, True), 3)
+    print(json.dumps({"step": "SearchForInitialization", "n1": len(k1), "n2": len(k2), "matches": int(n_gpu),
+                      "gpu_path_ms": round(t_gpu * 1e3, 3), "cpu_port_ms": round(t_cpu * 1e3, 3), "cpu_cores": 1,
+                      "note": "host arrays in and out; includes the copies and the host-side greedy pass"}))
+
+    # ---- SearchByBoW ----
+    for case in ((1, 1000, 1200, 120), (2, 2000, 2000, 40)):
+        k1, d1, v1, fv1, k2, d2, v2, fv2 = make_case(*case)
+        for name, kw in (("SearchByBoW(KeyFrame, Frame)", {}), ("SearchByBoW(KeyFrame, KeyFrame)", {"valid2": v2})):
+            n_gpu, _ = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, **kw)
+            t_gpu = best_of(lambda: hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, **kw), 5, 8)
+            t_cpu = best_of(lambda: orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, **kw), 3, 2)
+            print(json.dumps({"step": name, "n1": len(k1), "n2": len(k2), "nodes": len(fv1[0]), "matches": int(n_gpu),
+                              "gpu_path_ms": round(t_gpu * 1e3, 3), "cpu_port_ms": round(t_cpu * 1e3, 3),
+                              "cpu_cores": 1,
+                              "note": "host arrays in and out; includes the copies and the host-side greedy pass"}))
+
+if __name__ == "__main__":
+    main()
