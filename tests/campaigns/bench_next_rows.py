@@ -2,6 +2,7 @@
 """Timing of the steps either side of extraction, the GPU path beside the CPU oracle on the same inputs:
 
   undistort + grid      Frame::UndistortKeyPoints + AssignFeaturesToGrid, 256 frames of ~1000 keypoints, on the device
+  ComputeStereoMatches  Frame::ComputeStereoMatches on 128 extracted pairs (nFeatures 1200), on the device
   SearchForInitialization   two 2000-keypoint frames (the initialisation extractor), host arrays in and out
   SearchByBoW           both overloads, 1000 x 1200 features over 120 vocabulary nodes and 2000 x 2000 over 40,
                         host arrays in and out
@@ -73,6 +74,40 @@ def main():
     print(json.dumps({"step": "undistort + grid", "frames": B, "mean_keypoints": float(cnt.mean()),
                       "gpu_us_per_frame": round(t_gpu / B * 1e6, 3), "gpu_frames_per_s": round(B / t_gpu),
                       "cpu_port_us_per_frame": round(t_cpu * 1e6, 1), "cpu_cores": 1}))
+
+    # ---- ComputeStereoMatches (extraction not included on either side) ----
+    n = 128
+    left, right = m.synth_batch(5000, n), m.synth_batch(5000, n, right_view=True)
+    exl = m.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=n)
+    exr = m.ORBextractor(1200, 1.2, 8, 20, 7, max_batch=n)
+    scap = exl.capacity
+    outs = [(torch.zeros((n, scap, 7), dtype=torch.float32, device="cuda"),
+             torch.zeros((n, scap, 32), dtype=torch.uint8, device="cuda"),
+             torch.zeros(n, dtype=torch.int32, device="cuda")) for _ in range(2)]
+    d_left, d_right = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    exl.extract_batch_device(d_left, *outs[0])
+    exr.extract_batch_device(d_right, *outs[1])
+    exl.synchronize()
+    exr.synchronize()
+    bf, b = 47.90639384423901, 47.90639384423901 / 435.2046959714599
+    ur = torch.empty((n, scap), dtype=torch.float32, device="cuda")
+    z = torch.empty((n, scap), dtype=torch.float32, device="cuda")
+
+    def gpu_stereo():
+        hm.compute_stereo_matches_device(exl, exr, *outs[0], *outs[1], bf, b, ur, z)
+        hm.synchronize()
+    gpu_stereo()
+    t_gpu = best_of(gpu_stereo, 5, 4)
+    ol, orr = orc.Extractor(1200), orc.Extractor(1200)
+    t_cpu = 0.0
+    for p in range(4):
+        okl, odl = ol.extract(left[p])
+        okr, odr = orr.extract(right[p])
+        t_cpu += best_of(lambda: orc.compute_stereo_matches(ol, orr, okl, odl, okr, odr, bf, b), 3) / 4
+    print(json.dumps({"step": "ComputeStereoMatches", "pairs": n, "matched_per_pair": float((ur >= 0).sum().item()) / n,
+                      "gpu_us_per_pair": round(t_gpu / n * 1e6, 3), "gpu_pairs_per_s": round(n / t_gpu),
+                      "cpu_port_us_per_pair": round(t_cpu * 1e6, 1), "cpu_cores": 1}))
+    del exl, exr
 
     # ---- SearchForInitialization ----
     ex2 = m.ORBextractor(2000, 1.2, 8, 20, 7)
