@@ -7,7 +7,7 @@ already sits in HBM through the whole hot path (pyramid, FAST cells, quadtree, o
 outputs stay on the device.  N > 1: one process per GPU, every rank extracts its own frames, no
 data-path collective ("scaling": "weak").
 
-    python bench.py --gpus 1 --steps 64 --warmup 4
+    python bench.py --gpus 1 --steps 256 --warmup 16
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -46,14 +46,14 @@ STAGE_BYTES = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=256, help="frames per step and GPU")
     ap.add_argument("--unique", type=int, default=1024, help="distinct synthetic frames per GPU (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-hamming", action="store_true")
-    ap.add_argument("--contexts", type=int, default=2,
+    ap.add_argument("--contexts", type=int, default=3,
                     help="extractor contexts (HIP streams) a GPU alternates between; the tail of one step's "
                          "kernels overlaps the head of the next step's")
     return ap.parse_args()

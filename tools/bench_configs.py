@@ -56,54 +56,56 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     if "stereo" in which:
-        B, W, H, NF = 128, 752, 480, 1200
-        exl = m.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B)
-        exr = m.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B)
-        cap = exl.capacity
+        B, W, H, NF, SETS = 128, 752, 480, 1200, 2          # two sets of (left, right, matcher) in flight
         left = torch.from_numpy(m.synth_batch(rank * B, B, W, H)).cuda()
         right = torch.from_numpy(m.synth_batch(rank * B, B, W, H, right_view=True)).cuda()
-
-        def alloc():
-            return (torch.empty((B, cap, 7), dtype=torch.float32, device="cuda"),
-                    torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda"),
-                    torch.zeros(B, dtype=torch.int32, device="cuda"))
-        kl, dl, nl = alloc()
-        kr, dr, nr = alloc()
-        ur = torch.empty((B, cap), dtype=torch.float32, device="cuda")
-        z = torch.empty((B, cap), dtype=torch.float32, device="cuda")
-        hm = m.HammingMatcher(local)
         bf, b = 47.90639384423901, 47.90639384423901 / 435.2046959714599     # EuRoC stereo: Camera.bf, bf / fx
+        sets = []
+        for _ in range(SETS):
+            exl = m.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B)
+            exr = m.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B)
+            cap = exl.capacity
+
+            def alloc():
+                return (torch.empty((B, cap, 7), dtype=torch.float32, device="cuda"),
+                        torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                        torch.zeros(B, dtype=torch.int32, device="cuda"))
+            sets.append(dict(exl=exl, exr=exr, L=alloc(), R=alloc(), hm=m.HammingMatcher(local),
+                             ur=torch.empty((B, cap), dtype=torch.float32, device="cuda"),
+                             z=torch.empty((B, cap), dtype=torch.float32, device="cuda")))
 
         def step(i):
-            exl.extract_batch_device(left, kl, dl, nl)
-            exr.extract_batch_device(right, kr, dr, nr)
+            s = sets[i % SETS]
+            s["exl"].extract_batch_device(left, *s["L"])
+            s["exr"].extract_batch_device(right, *s["R"])
             # no host synchronisation: the call orders the three streams on the device (events)
-            hm.compute_stereo_matches_device(exl, exr, kl, dl, nl, kr, dr, nr, bf, b, ur, z)
-        steps = 16
-        dt = timed(torch, dist, world, step, steps, 2)
-        hm.synchronize()
+            s["hm"].compute_stereo_matches_device(s["exl"], s["exr"], *s["L"], *s["R"], bf, b, s["ur"], s["z"])
+        steps = 48
+        dt = timed(torch, dist, world, step, steps, 6)
+        for s in sets:
+            s["hm"].synchronize()
         if rank == 0:
-            matched = float((ur >= 0).sum().item()) / B
+            matched = float((sets[0]["ur"] >= 0).sum().item()) / B
             print(json.dumps({"workload": "configs[2] stereo pairs, 752x480, nFeatures 1200, extraction x2 + ComputeStereoMatches",
                               "value": round(world * B * steps / dt, 1), "unit": "stereo pairs/s", "n_gpus": world,
                               "pairs_per_step_per_gpu": B, "ms_per_step": round(dt / steps * 1e3, 3),
                               "mean_stereo_matches_per_pair": round(matched, 1), "collective": "none"}))
-        del exl, exr
+        del sets
 
     if "hd" in which:
-        B, W, H, NF = 64, 1920, 1080, 2000
-        ex = [m.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B) for _ in range(2)]
+        B, W, H, NF, NCTX = 64, 1920, 1080, 2000, 3        # three contexts in flight, like bench.py
+        ex = [m.ORBextractor(NF, 1.2, 8, 20, 7, device=local, max_width=W, max_height=H, max_batch=B) for _ in range(NCTX)]
         cap = ex[0].capacity
         frames = torch.from_numpy(m.synth_batch(rank * B, B, W, H)).cuda()
         outs = [(torch.empty((B, cap, 7), dtype=torch.float32, device="cuda"),
                  torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda"),
-                 torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(2)]
+                 torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(NCTX)]
 
         def step(i):
-            k, d, c = outs[i % 2]
-            ex[i % 2].extract_batch_device(frames, k, d, c)
-        steps = 16
-        dt = timed(torch, dist, world, step, steps, 2)
+            k, d, c = outs[i % NCTX]
+            ex[i % NCTX].extract_batch_device(frames, k, d, c)
+        steps = 48
+        dt = timed(torch, dist, world, step, steps, 6)
         if rank == 0:
             print(json.dumps({"workload": "configs[3] 1920x1080, nFeatures 2000, 8 levels", "n_gpus": world,
                               "value": round(world * B * steps / dt, 1), "unit": "frames/s",
