@@ -259,6 +259,41 @@ def test_two_contexts_like_stereo():
     assert np.array_equal(kl["x"], ckl["x"]) and np.array_equal(kr["y"], ckr["y"])
 
 
+def test_three_contexts_in_flight_give_the_serial_results():
+    """The throughput arrangement of bench.py: three contexts queue work back to back without any host
+    synchronisation, so their kernels share the CUs. Every output must equal the one-context, synchronised run."""
+    import torch
+    B, rounds = 8, 4
+    frames = torch.from_numpy(m.synth_batch(600, B * 3)).cuda()
+    exs = [m.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B) for _ in range(3)]
+    cap = exs[0].capacity
+
+    def alloc():
+        return (torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"),
+                torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                torch.zeros(B, dtype=torch.int32, device="cuda"))
+    want = []
+    for k in range(3):
+        o = alloc()
+        exs[0].extract_batch_device(frames[k * B:(k + 1) * B], *o)
+        exs[0].synchronize()
+        want.append(o)
+    outs = [alloc() for _ in range(3)]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for k in range(3):
+            exs[k].extract_batch_device(frames[k * B:(k + 1) * B], *outs[k])
+    for e in exs:
+        e.synchronize()
+    for k in range(3):
+        cnt = want[k][2].cpu().numpy()
+        assert np.array_equal(outs[k][2].cpu().numpy(), cnt) and cnt.min() > 900
+        for f in range(B):
+            # records hold ints too (class_id -1 reads as NaN in a float view): compare the bits
+            assert torch.equal(outs[k][0][f, :cnt[f]].view(torch.int32), want[k][0][f, :cnt[f]].view(torch.int32))
+            assert torch.equal(outs[k][1][f, :cnt[f]], want[k][1][f, :cnt[f]])
+
+
 def test_two_host_threads_like_the_reference_stereo_frame():
     """Frame's stereo constructor runs the left and right extractor on two threads at once
     (src/Frame.cc:97-110): two contexts driven concurrently from two host threads, many frames each."""
