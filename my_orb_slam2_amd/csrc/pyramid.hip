@@ -115,30 +115,25 @@ __global__ __launch_bounds__(256) void pyr_resize_dword_kernel(const uint8_t* __
     };
 
     // Consecutive destination rows usually share a source row (the lower row of one is the upper row of the
-    // next); its sums stay in hb.
-    int cachedSy = -1;       // source row whose sums sit in hb
-    uint32_t ha[4], hb[4] = {0, 0, 0, 0};
+    // next). The two sets of sums swap roles from row to row (the loop is unrolled by two with the names
+    // exchanged), so a shared row is never copied between registers.
+    int cachedSy = -1;       // source row whose sums sit in the set that is `up` next
+    uint32_t hA[4] = {0, 0, 0, 0}, hB[4] = {0, 0, 0, 0};
     const int dyEnd = min(dyBegin + kRowsPerThread, dh);
     const uint32_t* beta2 = reinterpret_cast<const uint32_t*>(tab.ibeta);   // (b0, b1) of a row as one dword
-    for (int dy = dyBegin; dy < dyEnd; dy++) {
+    auto row = [&](int dy, uint32_t (&up)[4], uint32_t (&lo)[4]) {
         int sy0 = tab.yofs[dy], sy1 = sy0 + 1;
         sy0 = min(max(sy0, 0), sh - 1);
         sy1 = min(max(sy1, 0), sh - 1);
         const uint32_t bb = beta2[dy];
-        if (sy0 == cachedSy) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) ha[k] = hb[k];
-        } else {
-            hrow(sy0, ha);
-        }
-        if (sy1 != sy0) {
-            hrow(sy1, hb);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) hb[k] = ha[k];
-        }
+        if (sy0 != cachedSy) hrow(sy0, up);
+        hrow(sy1, lo);       // (sy1 == sy0 only on rows clamped at the bottom edge: read again rather than copied)
         cachedSy = sy1;
-        vrow(dy, bb, ha, hb);
+        vrow(dy, bb, up, lo);
+    };
+    for (int dy = dyBegin; dy < dyEnd; dy += 2) {
+        row(dy, hA, hB);
+        if (dy + 1 < dyEnd) row(dy + 1, hB, hA);
     }
 }
 
