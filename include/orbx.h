@@ -246,6 +246,31 @@ int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* keys1_u
                                    float min_y, float max_x, float max_y, float* prev_matched, int window_size,
                                    float nnratio, int check_orientation, int32_t* matches12, int* nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * (src/ORBmatcher.cc:1372-1516; called from Tracking::TrackWithMotionModel, src/Tracking.cc:929-940), host arrays
+ * in and out, from the projection onwards. The pose algebra stays with the caller (:1382-1409): for each of the
+ * npts features of the last frame that carry a live map point and are no outliers, in LastFrame order, it passes
+ * the projection into the current frame proj_uv[2i], proj_uv[2i+1], inv_z[i] = invzc, the feature's octave
+ * (LastFrame.mvKeys[i].octave) and angle (LastFrame.mvKeysUn[i].angle), the map point's descriptor
+ * (pMP->GetDescriptor()) and has_observations[i] = pMP->Observations() > 0. direction: 0 = neither bForward nor
+ * bBackward (levels o-1..o+1), 1 = bForward (levels >= o), 2 = bBackward (levels <= o) (:1392-1393,
+ * :1429-1434). Current frame: keys_un = mvKeysUn, desc = mDescriptors, u_right = mvuRight (NULL = monocular),
+ * occupied[i] != 0 where mvpMapPoints[i] already holds a point with observations (NULL = none), cell_start /
+ * cell_items its grid. The frustum and image-bound tests (:1411-1420), the search radius th * scale_factors[o]
+ * (:1425), Frame::GetFeaturesInArea, the stereo consistency test (:1451-1457) and all distances run on the
+ * GPU in the reference's visiting order; the order-dependent part (what a feature already holds, best distance
+ * <= TH_HIGH, rotation histogram) runs on the host as written there. matches receives, per current-frame
+ * feature, the index into the npts list of the map point assigned to it (-1 = none); *nmatches the return
+ * value. */
+int orbx_search_by_projection_frame(orbx_matcher* m, const float* proj_uv, const float* inv_z,
+                                    const int32_t* last_octave, const float* last_angle, const uint8_t* desc_mp,
+                                    const uint8_t* has_observations, int npts, const orbx_keypoint* keys_un,
+                                    const uint8_t* desc, const float* u_right, const uint8_t* occupied, int n,
+                                    const int32_t* cell_start, const int32_t* cell_items, float min_x, float min_y,
+                                    float max_x, float max_y, const float* scale_factors, int nlevels, float th,
+                                    float mbf, int direction, int check_orientation, int32_t* matches,
+                                    int* nmatches);
+
 /* ORBmatcher::SearchByBoW, host arrays in and out. mode ORBX_BOW_KEYFRAME_FRAME follows
  * SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:153-293): side 1 is the keyframe
  * (keys1_un = mvKeysUn, valid1[i] != 0 where the keyframe holds a live map point), side 2 the frame

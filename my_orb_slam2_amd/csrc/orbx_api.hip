@@ -1027,6 +1027,91 @@ extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint
     return ORBX_OK;
 }
 
+namespace {
+// Shared by the windowed searches: checks the grid, sends queries, descriptors, keypoints and grid of the searched
+// frame through the pinned staging buffer in one copy, runs the candidate kernel and brings the packed lists back.
+// On return head = {total, counts[n1], offsets[n1]} and the candidates sit at m->pin.
+int run_window_search(orbx_matcher* m, const char* who, const std::vector<WindowQuery>& queries, const uint8_t* desc1,
+                      const orbx_keypoint* keys2, const uint8_t* desc2, const float* uright2, int n2,
+                      const int32_t* cell_start2, const int32_t* cell_items2, float min_x, float min_y, float max_x,
+                      float max_y, std::vector<int32_t>& head) {
+    const int n1 = (int)queries.size();
+    const int kCells = ORBX_GRID_COLS * ORBX_GRID_ROWS;
+    const int nItems = cell_start2[kCells];
+    {
+        // The kernel follows these indices: a grid that is not a partition of (a subset of) the frame's keypoints
+        // is refused here rather than read out of bounds there.
+        bool ok = cell_start2[0] == 0 && nItems >= 0 && nItems <= n2;
+        for (int c = 0; ok && c < kCells; c++) ok = cell_start2[c] <= cell_start2[c + 1];
+        std::vector<uint8_t> seen(ok ? (size_t)n2 : 0, 0);
+        for (int j = 0; ok && j < nItems; j++) {
+            const int32_t i2 = cell_items2[j];
+            ok = i2 >= 0 && i2 < n2 && !seen[i2];
+            if (ok) seen[i2] = 1;
+        }
+        if (!ok) {
+            set_error("%s: cell_start / cell_items do not describe a grid of the searched frame", who);
+            return ORBX_ERR_INVALID;
+        }
+    }
+    // an active query can meet every keypoint of the grid at most: the bound of the packed candidate list
+    long long active = 0;
+    for (const WindowQuery& q : queries) active += q.r >= 0.0f;
+    if (n2 > 0x7FFFFF || active * nItems > 0x3FFFFFFF) {
+        set_error("%s: too many keypoints (%d queries x %d)", who, n1, n2);
+        return ORBX_ERR_INVALID;
+    }
+    const int capTotal = (int)std::max(active * nItems, 1LL);
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    // inputs packed in pinned memory in the layout of the device scratch: one copy in
+    const size_t oQ = 0, oD1 = oQ + up(sizeof(WindowQuery) * n1), oK2 = oD1 + up(32 * (size_t)n1),
+                 oD2 = oK2 + up(sizeof(orbx_keypoint) * n2), oUr = oD2 + up(32 * (size_t)n2),
+                 oCs = oUr + up(uright2 ? 4 * (size_t)n2 : 0), oCi = oCs + up(4 * (size_t)(kCells + 1)),
+                 oHd = oCi + up(4 * (size_t)std::max(nItems, 1)),       // results: cursor, counts, offsets
+                 oCd = oHd + up(4 * (1 + 2 * (size_t)n1)), total = oCd + up(4 * (size_t)capTotal);
+    int rc = matcher_scratch(m, total, s);
+    if (rc) return rc;
+    if ((rc = matcher_pinned(m, oCd))) return rc;
+    uint8_t* base = static_cast<uint8_t*>(m->scratch);
+    std::memcpy(m->pin + oQ, queries.data(), sizeof(WindowQuery) * n1);
+    std::memcpy(m->pin + oD1, desc1, 32 * (size_t)n1);
+    std::memcpy(m->pin + oK2, keys2, sizeof(orbx_keypoint) * n2);
+    std::memcpy(m->pin + oD2, desc2, 32 * (size_t)n2);
+    if (uright2) std::memcpy(m->pin + oUr, uright2, 4 * (size_t)n2);
+    std::memcpy(m->pin + oCs, cell_start2, 4 * (size_t)(kCells + 1));
+    if (nItems > 0) std::memcpy(m->pin + oCi, cell_items2, 4 * (size_t)nItems);
+    HIP_TRY(hipMemcpyAsync(base, m->pin, oHd, hipMemcpyHostToDevice, s));
+    const float invW = static_cast<float>(ORBX_GRID_COLS) / (max_x - min_x);
+    const float invH = static_cast<float>(ORBX_GRID_ROWS) / (max_y - min_y);
+    int32_t* hd = reinterpret_cast<int32_t*>(base + oHd);
+    HIP_TRY(launch_window_candidates(n1, reinterpret_cast<const WindowQuery*>(base + oQ), base + oD1,
+                                     reinterpret_cast<const orbx_keypoint*>(base + oK2), base + oD2,
+                                     uright2 ? reinterpret_cast<const float*>(base + oUr) : nullptr,
+                                     reinterpret_cast<const int32_t*>(base + oCs),
+                                     reinterpret_cast<const int32_t*>(base + oCi), min_x, min_y, invW, invH, capTotal,
+                                     hd, hd + 1, hd + 1 + n1, reinterpret_cast<uint32_t*>(base + oCd), s));
+    HIP_TRY(hipMemcpyAsync(m->pin + oHd, base + oHd, 4 * (1 + 2 * (size_t)n1), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // the header leaves the pinned buffer before the buffer may grow for the candidate list
+    head.resize(1 + 2 * (size_t)n1);
+    std::memcpy(head.data(), m->pin + oHd, 4 * head.size());
+    const size_t ncand = (size_t)std::min(std::max(head[0], 0), capTotal);
+    if ((rc = matcher_pinned(m, std::max<size_t>(4 * ncand, 4)))) return rc;
+    if (ncand > 0) {
+        HIP_TRY(hipMemcpyAsync(m->pin, base + oCd, 4 * ncand, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    for (int i = 0; i < n1; i++)                      // a list must lie inside what was copied
+        if (head[1 + i] < 0 || head[1 + n1 + i] < 0 || (size_t)head[1 + n1 + i] + (size_t)head[1 + i] > ncand) {
+            set_error("%s: inconsistent candidate lists", who);
+            return ORBX_ERR_STATE;
+        }
+    return ORBX_OK;
+}
+}  // namespace
+
 extern "C" int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* keys1_un, const uint8_t* desc1,
                                               int n1, const orbx_keypoint* keys2_un, const uint8_t* desc2, int n2,
                                               const int32_t* cell_start2, const int32_t* cell_items2, float min_x,
@@ -1042,82 +1127,67 @@ extern "C" int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoi
     *nmatches = 0;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     if (n1 == 0 || n2 == 0) return ORBX_OK;
-    HIP_TRY(hipSetDevice(m->device));
-    hipStream_t s = m->stream;
-    const int kCells = ORBX_GRID_COLS * ORBX_GRID_ROWS;
-    const int nItems = cell_start2[kCells];
-    {
-        // The kernel follows these indices: a grid that is not a partition of (a subset of) frame 2's keypoints
-        // is refused here rather than read out of bounds there.
-        bool ok = cell_start2[0] == 0 && nItems >= 0 && nItems <= n2;
-        for (int c = 0; ok && c < kCells; c++) ok = cell_start2[c] <= cell_start2[c + 1];
-        std::vector<uint8_t> seen(ok ? (size_t)n2 : 0, 0);
-        for (int j = 0; ok && j < nItems; j++) {
-            const int32_t i2 = cell_items2[j];
-            ok = i2 >= 0 && i2 < n2 && !seen[i2];
-            if (ok) seen[i2] = 1;
-        }
-        if (!ok) {
-            set_error("orbx_search_for_initialization: cell_start2 / cell_items2 do not describe a grid of frame 2");
-            return ORBX_ERR_INVALID;
-        }
+    // one query per frame-1 keypoint of level 0 (:427-431): window around its previous match, level 0 only (:433)
+    std::vector<WindowQuery> queries(n1);
+    for (int i = 0; i < n1; i++) {
+        const int level1 = keys1_un[i].octave;
+        queries[i] = WindowQuery{prev_matched[2 * i], prev_matched[2 * i + 1], level1 > 0 ? -1.0f : (float)window_size,
+                                 0.0f, level1, level1};
     }
-    // a level-0 query can meet every level-0 keypoint of frame 2 at most: the bound of the packed candidate list
-    long long q0 = 0, t0 = 0;
-    for (int i = 0; i < n1; i++) q0 += keys1_un[i].octave <= 0;
-    for (int i = 0; i < n2; i++) t0 += keys2_un[i].octave == 0;
-    if (n2 > 0x7FFFFF || q0 * t0 > 0x3FFFFFFF) {
-        set_error("orbx_search_for_initialization: too many keypoints (%d x %d)", n1, n2);
-        return ORBX_ERR_INVALID;
-    }
-    const int capTotal = (int)std::max(q0 * t0, 1LL);
-    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    // inputs packed in pinned memory in the layout of the device scratch: one copy in
-    const size_t oK1 = 0, oD1 = oK1 + up(sizeof(orbx_keypoint) * n1), oK2 = oD1 + up(32 * (size_t)n1),
-                 oD2 = oK2 + up(sizeof(orbx_keypoint) * n2), oCs = oD2 + up(32 * (size_t)n2),
-                 oCi = oCs + up(4 * (size_t)(kCells + 1)), oPv = oCi + up(4 * (size_t)std::max(nItems, 1)),
-                 oHd = oPv + up(8 * (size_t)n1),                      // results: cursor, counts, offsets
-                 oCd = oHd + up(4 * (1 + 2 * (size_t)n1)), total = oCd + up(4 * (size_t)capTotal);
-    int rc = matcher_scratch(m, total, s);
+    std::vector<int32_t> head;
+    int rc = run_window_search(m, "orbx_search_for_initialization", queries, desc1, keys2_un, desc2, nullptr, n2,
+                               cell_start2, cell_items2, min_x, min_y, max_x, max_y, head);
     if (rc) return rc;
-    if ((rc = matcher_pinned(m, oCd))) return rc;
-    uint8_t* base = static_cast<uint8_t*>(m->scratch);
-    std::memcpy(m->pin + oK1, keys1_un, sizeof(orbx_keypoint) * n1);
-    std::memcpy(m->pin + oD1, desc1, 32 * (size_t)n1);
-    std::memcpy(m->pin + oK2, keys2_un, sizeof(orbx_keypoint) * n2);
-    std::memcpy(m->pin + oD2, desc2, 32 * (size_t)n2);
-    std::memcpy(m->pin + oCs, cell_start2, 4 * (size_t)(kCells + 1));
-    if (nItems > 0) std::memcpy(m->pin + oCi, cell_items2, 4 * (size_t)nItems);
-    std::memcpy(m->pin + oPv, prev_matched, 8 * (size_t)n1);
-    HIP_TRY(hipMemcpyAsync(base, m->pin, oHd, hipMemcpyHostToDevice, s));
-    const float invW = static_cast<float>(ORBX_GRID_COLS) / (max_x - min_x);
-    const float invH = static_cast<float>(ORBX_GRID_ROWS) / (max_y - min_y);
-    int32_t* hd = reinterpret_cast<int32_t*>(base + oHd);
-    HIP_TRY(launch_window_candidates(n1, reinterpret_cast<const orbx_keypoint*>(base + oK1), base + oD1,
-                                     reinterpret_cast<const orbx_keypoint*>(base + oK2), base + oD2,
-                                     reinterpret_cast<const int32_t*>(base + oCs),
-                                     reinterpret_cast<const int32_t*>(base + oCi),
-                                     reinterpret_cast<const float*>(base + oPv), min_x, min_y, invW, invH,
-                                     (float)window_size, capTotal, hd, hd + 1, hd + 1 + n1,
-                                     reinterpret_cast<uint32_t*>(base + oCd), s));
-    HIP_TRY(hipMemcpyAsync(m->pin + oHd, base + oHd, 4 * (1 + 2 * (size_t)n1), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    // the header leaves the pinned buffer before the buffer may grow for the candidate list
-    std::vector<int32_t> head(1 + 2 * (size_t)n1);
-    std::memcpy(head.data(), m->pin + oHd, 4 * head.size());
-    const size_t ncand = (size_t)std::min(std::max(head[0], 0), capTotal);
-    if ((rc = matcher_pinned(m, std::max<size_t>(4 * ncand, 4)))) return rc;
-    if (ncand > 0) {
-        HIP_TRY(hipMemcpyAsync(m->pin, base + oCd, 4 * ncand, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-    }
-    for (int i = 0; i < n1; i++)                      // a list must lie inside what was copied
-        if (head[1 + i] < 0 || head[1 + n1 + i] < 0 || (size_t)head[1 + n1 + i] + (size_t)head[1 + i] > ncand) {
-            set_error("orbx_search_for_initialization: inconsistent candidate lists");
-            return ORBX_ERR_STATE;
-        }
     *nmatches = replay_search_for_initialization(keys1_un, n1, keys2_un, n2, head.data() + 1, head.data() + 1 + n1,
                                                  reinterpret_cast<const uint32_t*>(m->pin), prev_matched, nnratio,
                                                  check_orientation != 0, matches12);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_projection_frame(orbx_matcher* m, const float* proj_uv, const float* inv_z,
+                                               const int32_t* last_octave, const float* last_angle,
+                                               const uint8_t* desc_mp, const uint8_t* has_observations, int npts,
+                                               const orbx_keypoint* keys_un, const uint8_t* desc,
+                                               const float* u_right, const uint8_t* occupied, int n,
+                                               const int32_t* cell_start, const int32_t* cell_items, float min_x,
+                                               float min_y, float max_x, float max_y, const float* scale_factors,
+                                               int nlevels, float th, float mbf, int direction,
+                                               int check_orientation, int32_t* matches, int* nmatches) {
+    if (!m || npts < 0 || n < 0 || !nmatches || !(max_x > min_x) || !(max_y > min_y) || !scale_factors ||
+        nlevels < 1 || nlevels > ORBX_MAX_LEVELS || direction < 0 || direction > 2 ||
+        (npts > 0 && (!proj_uv || !inv_z || !last_octave || !last_angle || !desc_mp || !has_observations)) ||
+        (n > 0 && (!keys_un || !desc || !cell_start || !cell_items || !matches))) {
+        set_error("orbx_search_by_projection_frame: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    *nmatches = 0;
+    for (int i = 0; i < n; i++) matches[i] = -1;
+    if (npts == 0 || n == 0) return ORBX_OK;
+    std::vector<WindowQuery> queries(npts);
+    for (int i = 0; i < npts; i++) {
+        WindowQuery q{0.f, 0.f, -1.0f, 0.f, 0, -1};
+        const float invzc = inv_z[i], u = proj_uv[2 * i], v = proj_uv[2 * i + 1];
+        const int o = last_octave[i];
+        // (:1411-1420; an octave outside the scale table is not something the extractor produces)
+        if (!(invzc < 0) && !(u < min_x || u > max_x) && !(v < min_y || v > max_y) && o >= 0 && o < nlevels) {
+            q.x = u;
+            q.y = v;
+            q.r = th * scale_factors[o];                       // :1425
+            q.ur = u - mbf * invzc;                            // :1453
+            if (direction == 1) { q.minLevel = o; q.maxLevel = -1; }            // bForward (:1430)
+            else if (direction == 2) { q.minLevel = 0; q.maxLevel = o; }        // bBackward (:1432)
+            else { q.minLevel = o - 1; q.maxLevel = o + 1; }                    // (:1434)
+            if (!(q.r >= 0.0f)) q.r = -1.0f;                   // a negative or NaN radius finds nothing
+        }
+        queries[i] = q;
+    }
+    std::vector<int32_t> head;
+    int rc = run_window_search(m, "orbx_search_by_projection_frame", queries, desc_mp, keys_un, desc, u_right, n,
+                               cell_start, cell_items, min_x, min_y, max_x, max_y, head);
+    if (rc) return rc;
+    *nmatches = replay_search_by_projection_frame(npts, head.data() + 1, head.data() + 1 + npts,
+                                                  reinterpret_cast<const uint32_t*>(m->pin), last_angle,
+                                                  has_observations, keys_un, occupied, n, check_orientation != 0,
+                                                  matches);
     return ORBX_OK;
 }

@@ -174,11 +174,21 @@ bool build_bow_rows(const uint32_t* nodes1, const int32_t* start1, const uint32_
 int replay_search_by_bow(int mode, const std::vector<BowRow>& rows, const uint16_t* dist, const uint32_t* items2,
                          const orbx_keypoint* k1, const orbx_keypoint* k2, const uint8_t* valid2, int n1, int n2,
                          float nnratio, bool checkOri, int32_t* matches);
-hipError_t launch_window_candidates(int n1, const orbx_keypoint* k1, const uint8_t* d1, const orbx_keypoint* k2,
-                                    const uint8_t* d2, const int32_t* cellStart, const int32_t* cellItems,
-                                    const float* prev, float minX, float minY, float invW, float invH, float r,
+// One windowed search over a frame's grid (Frame::GetFeaturesInArea, src/Frame.cc:365-418). r < 0: skipped.
+// ur is only read when the searched frame has right-image coordinates.
+struct WindowQuery {
+    float x, y, r, ur;
+    int32_t minLevel, maxLevel;
+};
+hipError_t launch_window_candidates(int n1, const WindowQuery* queries, const uint8_t* d1, const orbx_keypoint* k2,
+                                    const uint8_t* d2, const float* uRight2, const int32_t* cellStart,
+                                    const int32_t* cellItems, float minX, float minY, float invW, float invH,
                                     int capTotal, int32_t* cursor, int32_t* candCount, int32_t* candOffset,
                                     uint32_t* cand, hipStream_t s);
+int replay_search_by_projection_frame(int npts, const int32_t* candCount, const int32_t* candOffset,
+                                      const uint32_t* cand, const float* lastAngle, const uint8_t* hasObs,
+                                      const orbx_keypoint* k2, const uint8_t* occupied2, int n2, bool checkOri,
+                                      int32_t* match2);
 int replay_search_for_initialization(const orbx_keypoint* k1, int n1, const orbx_keypoint* k2, int n2,
                                      const int32_t* candCount, const int32_t* candOffset, const uint32_t* cand,
                                      float* prev, float nnratio, bool checkOri, int32_t* matches12);

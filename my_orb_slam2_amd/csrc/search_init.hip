@@ -1,4 +1,6 @@
-// ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:413-530).
+// ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:413-530) and
+// ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (:1372-1516): the windowed searches over the
+// current frame's 64 x 48 grid.
 //
 // The data-parallel part — Frame::GetFeaturesInArea (src/Frame.cc:365-418) for every level-0 keypoint of
 // frame 1 and ORBmatcher::DescriptorDistance (:1698-1714) to every candidate — runs on the GPU, one wave
@@ -24,13 +26,13 @@ struct GridParams {
 // rows inside, :387-410), are taken 64 at a time, one cell per lane, so the dependent loads of a cell (its start,
 // its keypoint indices, their positions) run side by side for 64 cells; a prefix sum over the lanes' counts puts
 // every cell's candidates where the sequential walk would have put them.
-__global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const orbx_keypoint* __restrict__ k1,
+__global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const WindowQuery* __restrict__ queries,
                                                                 const uint4* __restrict__ d1,
                                                                 const orbx_keypoint* __restrict__ k2,
                                                                 const uint4* __restrict__ d2,
+                                                                const float* __restrict__ uRight2,
                                                                 const int32_t* __restrict__ cellStart,
-                                                                const int32_t* __restrict__ cellItems,
-                                                                const float* __restrict__ prev, GridParams gp, float r,
+                                                                const int32_t* __restrict__ cellItems, GridParams gp,
                                                                 int capTotal, int32_t* __restrict__ cursor,
                                                                 int32_t* __restrict__ candCount,
                                                                 int32_t* __restrict__ candOffset,
@@ -39,9 +41,10 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const or
     const int i1 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (i1 >= n1) return;
     int total = 0, offset = 0;
-    if (k1[i1].octave <= 0) {                                  // level1 > 0: continue (:429-431)
-        const float x = prev[2 * i1], y = prev[2 * i1 + 1];
-        // GetFeaturesInArea(x, y, r, 0, 0)
+    const WindowQuery q = queries[i1];
+    if (q.r >= 0.0f) {                                         // r < 0: the caller skips this query
+        const float x = q.x, y = q.y, r = q.r;
+        // GetFeaturesInArea(x, y, r, minLevel, maxLevel)
         const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, gp.minX), r), gp.invW)));
         const int nMaxCellX = min(ORBX_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, gp.minX), r), gp.invW)));
         const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, gp.minY), r), gp.invH)));
@@ -61,9 +64,17 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const or
             };
             auto passes = [&](int i2) {
                 const orbx_keypoint kp = k2[i2];
-                if (kp.octave < 0 || kp.octave > 0) return false;                  // minLevel = maxLevel = 0
+                // (src/Frame.cc:399-406; with bCheckLevels false both limits are below every octave)
+                if (kp.octave < q.minLevel || (q.maxLevel >= 0 && kp.octave > q.maxLevel)) return false;
                 const float distx = __fsub_rn(kp.x, x), disty = __fsub_rn(kp.y, y);
-                return fabsf(distx) < r && fabsf(disty) < r;
+                if (!(fabsf(distx) < r && fabsf(disty) < r)) return false;
+                // stereo consistency of SearchByProjection (src/ORBmatcher.cc:1451-1457); it does not depend on
+                // the order of the queries, unlike the test on what the feature already holds
+                if (uRight2 != nullptr) {
+                    const float ur2 = uRight2[i2];
+                    if (ur2 > 0 && fabsf(__fsub_rn(q.ur, ur2)) > r) return false;
+                }
+                return true;
             };
             auto wave_incl_scan = [&](int v) {
 #pragma unroll
@@ -206,19 +217,75 @@ int replay_search_for_initialization(const orbx_keypoint* k1, int n1, const orbx
     return nmatches;
 }
 
-hipError_t launch_window_candidates(int n1, const orbx_keypoint* k1, const uint8_t* d1, const orbx_keypoint* k2,
-                                    const uint8_t* d2, const int32_t* cellStart, const int32_t* cellItems,
-                                    const float* prev, float minX, float minY, float invW, float invH, float r,
+hipError_t launch_window_candidates(int n1, const WindowQuery* queries, const uint8_t* d1, const orbx_keypoint* k2,
+                                    const uint8_t* d2, const float* uRight2, const int32_t* cellStart,
+                                    const int32_t* cellItems, float minX, float minY, float invW, float invH,
                                     int capTotal, int32_t* cursor, int32_t* candCount, int32_t* candOffset,
                                     uint32_t* cand, hipStream_t s) {
     if (n1 <= 0) return hipSuccess;
     GridParams gp{minX, minY, invW, invH};
     hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(window_candidates_kernel, dim3((n1 + 3) / 4), dim3(256), 0, s, n1, k1,
-                       reinterpret_cast<const uint4*>(d1), k2, reinterpret_cast<const uint4*>(d2), cellStart,
-                       cellItems, prev, gp, r, capTotal, cursor, candCount, candOffset, cand);
+    hipLaunchKernelGGL(window_candidates_kernel, dim3((n1 + 3) / 4), dim3(256), 0, s, n1, queries,
+                       reinterpret_cast<const uint4*>(d1), k2, reinterpret_cast<const uint4*>(d2), uRight2, cellStart,
+                       cellItems, gp, capTotal, cursor, candCount, candOffset, cand);
     return hipGetLastError();
+}
+
+// Host half of SearchByProjection(Frame&, const Frame&, ...): src/ORBmatcher.cc:1441-1513 over the GPU-made
+// candidate lists (level, window and stereo tests already applied). What a feature of the current frame holds
+// changes as the loop goes, so the best match of a map point depends on the points before it.
+int replay_search_by_projection_frame(int npts, const int32_t* candCount, const int32_t* candOffset,
+                                      const uint32_t* cand, const float* lastAngle, const uint8_t* hasObs,
+                                      const orbx_keypoint* k2, const uint8_t* occupied2, int n2, bool checkOri,
+                                      int32_t* match2) {
+    const int HISTO_LENGTH = 30, TH_HIGH = 100;   // include/PresetParameters.h:11-13
+    std::vector<uint8_t> blocked(n2, 0);          // mvpMapPoints[i2] && mvpMapPoints[i2]->Observations() > 0
+    for (int i = 0; i < n2; i++) {
+        match2[i] = -1;
+        blocked[i] = occupied2 ? (occupied2[i] != 0) : 0;
+    }
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int i = 0; i < npts; i++) {
+        const int nc = candCount[i];
+        if (nc == 0) continue;
+        const uint32_t* list = cand + candOffset[i];
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = (int)(list[c] & 0x7FFFFFu), dist = (int)(list[c] >> 23);
+            if (blocked[i2]) continue;
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = i2;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            match2[bestIdx2] = i;
+            blocked[bestIdx2] = hasObs[i] != 0;
+            nmatches++;
+            if (checkOri) {
+                float rot = lastAngle[i] - k2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot / (360 * factor));
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx2 : rotHist[i]) {         // unconditional, as in the reference (:1506-1510)
+                match2[idx2] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
 }
 
 }  // namespace orbx

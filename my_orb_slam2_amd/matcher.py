@@ -148,6 +148,41 @@ class HammingMatcher:
             "orbx_search_for_initialization")
         return n.value, out
 
+    def search_by_projection_frame(self, proj_uv, inv_z, last_octave, last_angle, desc_mp, has_observations,
+                                   keys_un, desc, cell_start, cell_items, bounds, scale_factors, th, mbf=0.0,
+                                   direction=0, u_right=None, occupied=None, check_orientation=True):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1372-1516) from the
+        projection onwards; Tracking calls it with ORBmatcher(0.9, true) and th = 15 (7 for stereo), then 2 * th
+        (src/Tracking.cc:929-940). Host numpy arrays; see include/orbx.h for the meaning of every argument.
+        Returns (nmatches, matches) with one entry per current-frame feature."""
+        from ._lib import KEYPOINT_DTYPE
+        uv = np.ascontiguousarray(proj_uv, dtype=np.float32).reshape(-1, 2)
+        iz = np.ascontiguousarray(inv_z, dtype=np.float32)
+        lo = np.ascontiguousarray(last_octave, dtype=np.int32)
+        la = np.ascontiguousarray(last_angle, dtype=np.float32)
+        dm = np.ascontiguousarray(desc_mp, dtype=np.uint8).reshape(-1, 32)
+        ho = np.ascontiguousarray(has_observations, dtype=np.uint8)
+        k2 = np.ascontiguousarray(keys_un, dtype=KEYPOINT_DTYPE)
+        d2 = np.ascontiguousarray(desc, dtype=np.uint8)
+        cs = np.ascontiguousarray(cell_start, dtype=np.int32)
+        ci = np.ascontiguousarray(cell_items, dtype=np.int32)
+        sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, dtype=np.float32)
+        oc = None if occupied is None else np.ascontiguousarray(occupied, dtype=np.uint8)
+        npts = len(uv)
+        assert len(iz) == npts and len(lo) == npts and len(la) == npts and len(dm) == npts and len(ho) == npts
+        assert ur is None or len(ur) == len(k2)
+        assert oc is None or len(oc) == len(k2)
+        out = np.empty(len(k2), dtype=np.int32)
+        n = C.c_int(0)
+        check(lib().orbx_search_by_projection_frame(
+            self._m, np_ptr(uv), np_ptr(iz), np_ptr(lo), np_ptr(la), np_ptr(dm), np_ptr(ho), npts, np_ptr(k2),
+            np_ptr(d2), None if ur is None else np_ptr(ur), None if oc is None else np_ptr(oc), len(k2), np_ptr(cs),
+            np_ptr(ci), float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), np_ptr(sf), len(sf),
+            float(th), float(mbf), int(direction), 1 if check_orientation else 0, np_ptr(out), C.byref(n)),
+            "orbx_search_by_projection_frame")
+        return n.value, out
+
     def search_by_bow(self, keys1_un, desc1, valid1, fv1, keys2, desc2, fv2, valid2=None, nnratio=0.7,
                       check_orientation=True):
         """ORBmatcher::SearchByBoW. valid2 None: the KeyFrame x Frame overload (src/ORBmatcher.cc:153-293,

@@ -1156,3 +1156,118 @@ extern "C" int orc_search_by_bow(int mode, const orc_keypoint* k1, const uint8_t
     }
     return nmatches;
 }
+
+/* ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono), src/ORBmatcher.cc:1395-1515 (the pose algebra
+ * of :1382-1409 is the caller's). */
+extern "C" int orc_search_by_projection_frame(const float* uv, const float* invz, const int32_t* last_octave,
+                                              const float* last_angle, const uint8_t* desc_mp,
+                                              const uint8_t* has_obs, int npts, const orc_keypoint* k2,
+                                              const uint8_t* d2, const float* uright2, const uint8_t* occupied2,
+                                              int n2, float minX, float minY, float maxX, float maxY,
+                                              const float* scale_factors, int nlevels, float th, float mbf,
+                                              int direction, int checkOri, int32_t* match2) {
+    const int COLS = 64, ROWS = 48, HISTO_LENGTH = 30, TH_HIGH = 100;
+    const float invW = static_cast<float>(COLS) / (maxX - minX), invH = static_cast<float>(ROWS) / (maxY - minY);
+    std::vector<std::vector<uint32_t>> grid(COLS * ROWS);   /* mGrid of the current frame (src/Frame.cc:268-283) */
+    for (int i = 0; i < n2; i++) {
+        const int posX = (int)std::round((k2[i].x - minX) * invW), posY = (int)std::round((k2[i].y - minY) * invH);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        grid[posX * ROWS + posY].push_back((uint32_t)i);
+    }
+    /* Frame::GetFeaturesInArea (src/Frame.cc:365-418) */
+    auto features_in_area = [&](float x, float y, float r, int minLevel, int maxLevel) {
+        std::vector<size_t> v;
+        const int nMinCellX = std::max(0, (int)std::floor((x - minX - r) * invW));
+        if (nMinCellX >= COLS) return v;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - minX + r) * invW));
+        if (nMaxCellX < 0) return v;
+        const int nMinCellY = std::max(0, (int)std::floor((y - minY - r) * invH));
+        if (nMinCellY >= ROWS) return v;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - minY + r) * invH));
+        if (nMaxCellY < 0) return v;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (uint32_t j : grid[ix * ROWS + iy]) {
+                    const orc_keypoint& kp = k2[j];
+                    if (bCheckLevels) {
+                        if (kp.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                    }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) v.push_back(j);
+                }
+        return v;
+    };
+    /* CurrentFrame.mvpMapPoints as far as this function looks at it: who sits there, and has it observations */
+    std::vector<int32_t> holder(n2, -1);
+    std::vector<uint8_t> blocked(n2, 0);
+    for (int i = 0; i < n2; i++) blocked[i] = occupied2 ? (occupied2[i] != 0) : 0;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    const bool bForward = direction == 1, bBackward = direction == 2;
+    for (int i = 0; i < npts; i++) {
+        const float invzc = invz[i];
+        if (invzc < 0) continue;                                            /* :1411 */
+        const float u = uv[2 * i], v = uv[2 * i + 1];
+        if (u < minX || u > maxX) continue;                                 /* :1417-1420 */
+        if (v < minY || v > maxY) continue;
+        const int nLastOctave = last_octave[i];
+        if (nLastOctave < 0 || nLastOctave >= nlevels) continue;            /* (not a value the extractor produces) */
+        const float radius = th * scale_factors[nLastOctave];               /* :1425 */
+        std::vector<size_t> vIndices2;
+        if (bForward) vIndices2 = features_in_area(u, v, radius, nLastOctave, -1);
+        else if (bBackward) vIndices2 = features_in_area(u, v, radius, 0, nLastOctave);
+        else vIndices2 = features_in_area(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = desc_mp + 32 * (size_t)i;
+        int bestDist = 256, bestIdx2 = -1;
+        for (size_t i2 : vIndices2) {
+            if (blocked[i2]) continue;                                      /* :1447-1449 */
+            if (uright2 && uright2[i2] > 0) {                               /* :1451-1457 */
+                const float ur = u - mbf * invzc;
+                const float er = std::fabs(ur - uright2[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = orc_hamming256(dMP, d2 + 32 * i2);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = (int)i2;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            holder[bestIdx2] = i;                                           /* :1472 */
+            blocked[bestIdx2] = has_obs[i] != 0;
+            nmatches++;
+            if (checkOri) {
+                float rot = last_angle[i] - k2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::round(rot / (360 * factor));
+                if (bin == HISTO_LENGTH) bin = 0;
+                if (bin >= 0 && bin < HISTO_LENGTH) rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < HISTO_LENGTH; i++) { /* ComputeThreeMaxima (:1652-1693) */
+            const int s = (int)rotHist[i].size();
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx2 : rotHist[i]) {                                   /* :1506-1510: unconditional */
+                holder[idx2] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < n2; i++) match2[i] = holder[i];
+    return nmatches;
+}
+

@@ -136,6 +136,22 @@ int   orc_search_by_bow(int mode, const orc_keypoint* k1, const uint8_t* d1, con
                         const uint32_t* nodes2, const int32_t* start2, const uint32_t* items2, int nn2,
                         float nnratio, int check_orientation, int32_t* out);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * (src/ORBmatcher.cc:1372-1516) from the projection onwards: the caller has run lines :1382-1409 and hands over,
+ * for each of the npts last-frame features that carry a live map point and are no outliers (in LastFrame order),
+ * the projection (u, v), invzc, the feature's octave and angle (LastFrame.mvKeys / mvKeysUn), the map point's
+ * descriptor and whether the map point has observations. direction: 0 = neither forward nor backward
+ * (levels o-1..o+1), 1 = bForward (levels >= o), 2 = bBackward (levels <= o) (:1392-1393, :1429-1434).
+ * uright2 NULL = monocular (mvuRight all -1); occupied2[i] != 0 where CurrentFrame.mvpMapPoints[i] already
+ * holds a point with observations (NULL = none). match2[i] receives the index (into the npts list) of the
+ * map point assigned to current feature i, or -1. Returns nmatches. */
+int   orc_search_by_projection_frame(const float* uv, const float* invz, const int32_t* last_octave,
+                                     const float* last_angle, const uint8_t* desc_mp, const uint8_t* has_obs,
+                                     int npts, const orc_keypoint* k2, const uint8_t* d2, const float* uright2,
+                                     const uint8_t* occupied2, int n2, float minX, float minY, float maxX,
+                                     float maxY, const float* scale_factors, int nlevels, float th, float mbf,
+                                     int direction, int check_orientation, int32_t* match2);
+
 #ifdef __cplusplus
 }
 #endif

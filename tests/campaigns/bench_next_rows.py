@@ -4,6 +4,7 @@
   undistort + grid      Frame::UndistortKeyPoints + AssignFeaturesToGrid, 256 frames of ~1000 keypoints, on the device
   ComputeStereoMatches  Frame::ComputeStereoMatches on 128 extracted pairs (nFeatures 1200), on the device
   SearchForInitialization   two 2000-keypoint frames (the initialisation extractor), host arrays in and out
+  SearchByProjection    (CurrentFrame, LastFrame): ~700 map points into a 1000-keypoint frame, th 15
   SearchByBoW           both overloads, 1000 x 1200 features over 120 vocabulary nodes and 2000 x 2000 over 40,
                         host arrays in and out
 
@@ -121,6 +122,19 @@ def main():
     t_cpu = best_of(lambda: orc.search_for_initialization(k1, d1, k2, d2, b0, prev.copy(), 100, 0.9, True), 3)
     print(json.dumps({"step": "SearchForInitialization", "n1": len(k1), "n2": len(k2), "matches": int(n_gpu),
                       "gpu_path_ms": round(t_gpu * 1e3, 3), "cpu_port_ms": round(t_cpu * 1e3, 3), "cpu_cores": 1,
+                      "note": "host arrays in and out; includes the copies and the host-side greedy pass"}))
+
+    # ---- SearchByProjection(CurrentFrame, LastFrame) ----
+    from tests.test_gpu_search_projection import make_case as proj_case, BOUNDS
+    c = proj_case(1, 15, 0, False)
+    pa = (c["uv"], c["inv_z"], c["last_octave"], c["last_angle"], c["desc_mp"], c["has_obs"])
+    n_gpu, _ = hm.search_by_projection_frame(*pa, c["kc"], c["dc"], c["start"], c["items"], BOUNDS, c["sf"], c["th"])
+    t_gpu = best_of(lambda: hm.search_by_projection_frame(*pa, c["kc"], c["dc"], c["start"], c["items"], BOUNDS,
+                                                          c["sf"], c["th"]), 5, 8)
+    t_cpu = best_of(lambda: orc.search_by_projection_frame(*pa, c["kc"], c["dc"], BOUNDS, c["sf"], c["th"]), 3, 2)
+    print(json.dumps({"step": "SearchByProjection(Frame, LastFrame)", "map_points": len(c["uv"]), "n": len(c["kc"]),
+                      "th": c["th"], "matches": int(n_gpu), "gpu_path_ms": round(t_gpu * 1e3, 3),
+                      "cpu_port_ms": round(t_cpu * 1e3, 3), "cpu_cores": 1,
                       "note": "host arrays in and out; includes the copies and the host-side greedy pass"}))
 
     # ---- SearchByBoW ----

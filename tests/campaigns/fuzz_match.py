@@ -30,7 +30,7 @@ def main():
     from tests import oracle as orc
     rng = np.random.default_rng(a.seed)
     hm = m.HammingMatcher()
-    done = {"knn": 0, "stereo_pairs": 0, "stereo_matches": 0, "grid_frames": 0, "init_matches": 0}
+    done = {"knn": 0, "stereo_pairs": 0, "stereo_matches": 0, "grid_frames": 0, "init_matches": 0, "projection_matches": 0}
 
     for case in range(a.cases):
         # ---- kNN ----
@@ -144,6 +144,35 @@ def main():
         if n != want_n or not np.array_equal(got, want) or not np.array_equal(p_g, want_prev):
             fail("search_for_initialization", dict(case=case, w=w, h=h, nf=nf, idx=idx0, window=window, ratio=ratio, ori=ori))
         done["init_matches"] += n
+
+        # ---- SearchByProjection(current = right view, last = left view): random flow, depths, occupancy ----
+        if len(k1) and len(k2):
+            pick = np.flatnonzero(rng.random(len(k1)) < rng.uniform(0.2, 1.0))
+            npts = len(pick)
+            uv = (np.stack([k1["x"][pick], k1["y"][pick]], 1) + rng.normal(0, float(rng.uniform(0.5, 8)), (npts, 2))
+                  ).astype(np.float32)
+            uv[:, 0] -= rng.uniform(0, 40, npts).astype(np.float32)
+            inv_z = rng.uniform(0.01, 1.0, npts).astype(np.float32)
+            inv_z[rng.random(npts) < 0.05] *= -1
+            uv[rng.random(npts) < 0.05] += np.float32(w)
+            dmp = d1[pick].copy()
+            flips = rng.integers(0, 256, (npts, 32), dtype=np.uint8) & rng.integers(0, 256, (npts, 32), dtype=np.uint8)
+            dmp ^= flips & np.uint8(rng.choice([0x01, 0x11, 0x55]))
+            has_obs = (rng.random(npts) < 0.8).astype(np.uint8)
+            occ = (rng.random(len(k2)) < 0.15).astype(np.uint8) if rng.random() < 0.7 else None
+            stereo = rng.random() < 0.5
+            ur2 = np.where(rng.random(len(k2)) < 0.6, k2["x"] - rng.uniform(0, 40, len(k2)), -1).astype(np.float32) if stereo else None
+            th = float(rng.choice([7, 14, 15, 30]))
+            direction = int(rng.integers(0, 3)) if stereo else 0
+            sfac = exl.GetScaleFactors()
+            pargs = (uv, inv_z, k1["octave"][pick].astype(np.int32), k1["angle"][pick].astype(np.float32), dmp, has_obs)
+            want_n, want = orc.search_by_projection_frame(*pargs, k2, d2, ib, sfac, th, bf, direction, ur2, occ, ori)
+            n, got = hm.search_by_projection_frame(*pargs, k2, d2, s2, i2 if len(i2) else np.zeros(1, np.int32), ib, sfac,
+                                                   th, bf, direction, ur2, occ, ori)
+            if n != want_n or not np.array_equal(got, want):
+                fail("search_by_projection_frame", dict(case=case, w=w, h=h, nf=nf, idx=idx0, th=th, direction=direction,
+                                                        stereo=stereo, ori=ori, n=n, want_n=want_n))
+            done["projection_matches"] += n
         exl.close()
         exr.close()
     print(json.dumps(dict(cases=a.cases, seed=a.seed, differences=0, **done)))

@@ -81,6 +81,10 @@ def lib():
         L.orc_search_by_bow.restype = C.c_int
         L.orc_search_by_bow.argtypes = [C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int,
                                         _P, _P, _P, C.c_int, C.c_float, C.c_int, _P]
+        L.orc_search_by_projection_frame.restype = C.c_int
+        L.orc_search_by_projection_frame.argtypes = [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int,
+                                                     C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int,
+                                                     C.c_float, C.c_float, C.c_int, C.c_int, _P]
         _LIB = L
     return _LIB
 
@@ -278,3 +282,26 @@ def search_by_bow(k1, d1, valid1, fv1, k2, d2, fv2, valid2=None, nnratio=0.7, ch
                                 ptr(k2), ptr(d2), None if v2 is None else ptr(v2), len(k2), ptr(b[0]), ptr(b[1]),
                                 ptr(b[2]), len(b[0]), nnratio, 1 if check_ori else 0, ptr(out))
     return n, out
+
+
+def search_by_projection_frame(uv, inv_z, last_octave, last_angle, desc_mp, has_obs, k2, d2, bounds, scale_factors,
+                               th, mbf=0.0, direction=0, u_right=None, occupied=None, check_ori=True):
+    uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    iz = np.ascontiguousarray(inv_z, dtype=np.float32)
+    lo = np.ascontiguousarray(last_octave, dtype=np.int32)
+    la = np.ascontiguousarray(last_angle, dtype=np.float32)
+    dm = np.ascontiguousarray(desc_mp, dtype=np.uint8).reshape(-1, 32)
+    ho = np.ascontiguousarray(has_obs, dtype=np.uint8)
+    k2 = np.ascontiguousarray(k2, dtype=KP)
+    d2 = np.ascontiguousarray(d2, dtype=np.uint8)
+    sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, dtype=np.float32)
+    oc = None if occupied is None else np.ascontiguousarray(occupied, dtype=np.uint8)
+    out = np.empty(len(k2), dtype=np.int32)
+    n = lib().orc_search_by_projection_frame(ptr(uv), ptr(iz), ptr(lo), ptr(la), ptr(dm), ptr(ho), len(uv), ptr(k2),
+                                             ptr(d2), None if ur is None else ptr(ur),
+                                             None if oc is None else ptr(oc), len(k2), bounds[0], bounds[1],
+                                             bounds[2], bounds[3], ptr(sf), len(sf), th, mbf, direction,
+                                             1 if check_ori else 0, ptr(out))
+    return n, out
+

@@ -425,3 +425,126 @@ def test_search_by_bow_against_python_restatement():
                 assert got_n == want_n and np.array_equal(got, want)
                 seen += want_n
     assert seen > 20
+
+
+def test_search_by_projection_against_python_restatement():
+    """orc_search_by_projection_frame against a direct Python transcription of src/ORBmatcher.cc:1395-1513 with
+    Frame::GetFeaturesInArea (src/Frame.cc:365-418) on random keypoints (float32 arithmetic spelled out)."""
+    f32 = np.float32
+    rng = np.random.default_rng(3)
+    n2, npts = 400, 260
+    bounds = (f32(0), f32(0), f32(752), f32(480))
+    k2 = np.zeros(n2, orc.KP)
+    k2["x"] = rng.uniform(0, 752, n2).astype(f32)
+    k2["y"] = rng.uniform(0, 480, n2).astype(f32)
+    k2["octave"] = rng.integers(0, 8, n2)
+    k2["angle"] = rng.uniform(0, 360, n2).astype(f32)
+    d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    src = rng.integers(0, n2, npts)
+    uv = np.stack([k2["x"][src], k2["y"][src]], 1).astype(f32) + rng.normal(0, 3, (npts, 2)).astype(f32)
+    uv[rng.random(npts) < 0.05] += f32(800)
+    inv_z = rng.uniform(0.05, 1, npts).astype(f32)
+    inv_z[rng.random(npts) < 0.05] *= -1
+    octs = np.clip(k2["octave"][src] + rng.integers(-1, 2, npts), 0, 7).astype(np.int32)
+    ang = np.mod(k2["angle"][src] + np.where(rng.random(npts) < 0.7, 20, rng.uniform(0, 360, npts)), 360).astype(f32)
+    dm = d2[src] ^ (rng.integers(0, 256, (npts, 32), dtype=np.uint8) & rng.integers(0, 256, (npts, 32), dtype=np.uint8)
+                    & 0x11)
+    has_obs = (rng.random(npts) < 0.8).astype(np.uint8)
+    occupied = (rng.random(n2) < 0.1).astype(np.uint8)
+    ur2 = np.where(rng.random(n2) < 0.5, k2["x"] - rng.uniform(0, 30, n2), -1).astype(f32)
+    sf = np.cumprod([1.0] + [1.2] * 7).astype(f32)
+    ham = lambda a, b: int(np.unpackbits(a ^ b).sum())
+    minX, minY, maxX, maxY = bounds
+    invW, invH = f32(64) / f32(maxX - minX), f32(48) / f32(maxY - minY)
+    rnd = lambda q: int(np.floor(q + 0.5)) if q >= 0 else int(np.ceil(q - 0.5))
+    grid = {}
+    for i in range(n2):
+        px, py = rnd(float(f32(f32(k2["x"][i] - minX) * invW))), rnd(float(f32(f32(k2["y"][i] - minY) * invH)))
+        if 0 <= px < 64 and 0 <= py < 48:
+            grid.setdefault((px, py), []).append(i)
+
+    def area(x, y, r, lo, hi):
+        out = []
+        x0 = max(0, int(np.floor(f32(f32(f32(x - minX) - r) * invW))))
+        x1 = min(63, int(np.ceil(f32(f32(f32(x - minX) + r) * invW))))
+        y0 = max(0, int(np.floor(f32(f32(f32(y - minY) - r) * invH))))
+        y1 = min(47, int(np.ceil(f32(f32(f32(y - minY) + r) * invH))))
+        if x0 >= 64 or x1 < 0 or y0 >= 48 or y1 < 0:
+            return out
+        check = lo > 0 or hi >= 0
+        for ix in range(x0, x1 + 1):
+            for iy in range(y0, y1 + 1):
+                for j in grid.get((ix, iy), []):
+                    o = int(k2["octave"][j])
+                    if check and (o < lo or (hi >= 0 and o > hi)):
+                        continue
+                    if abs(f32(k2["x"][j] - x)) < r and abs(f32(k2["y"][j] - y)) < r:
+                        out.append(j)
+        return out
+
+    def restate(th, mbf, direction, stereo, check_ori):
+        holder = [-1] * n2
+        blocked = [bool(b) for b in occupied]
+        hist = [[] for _ in range(30)]
+        factor = f32(1.0) / f32(30)
+        n = 0
+        for i in range(npts):
+            iz, u, v = inv_z[i], uv[i, 0], uv[i, 1]
+            if iz < 0 or u < minX or u > maxX or v < minY or v > maxY:
+                continue
+            o = int(octs[i])
+            radius = f32(f32(th) * sf[o])
+            lo, hi = ((o, -1) if direction == 1 else (0, o) if direction == 2 else (o - 1, o + 1))
+            best, bidx = 256, -1
+            for j in area(u, v, radius, lo, hi):
+                if blocked[j]:
+                    continue
+                if stereo and ur2[j] > 0:
+                    ur = f32(u - f32(f32(mbf) * iz))
+                    if abs(f32(ur - ur2[j])) > radius:
+                        continue
+                dist = ham(dm[i], d2[j])
+                if dist < best:
+                    best, bidx = dist, j
+            if best <= 100:
+                holder[bidx] = i
+                blocked[bidx] = bool(has_obs[i])
+                n += 1
+                if check_ori:
+                    rot = f32(ang[i] - k2["angle"][bidx])
+                    if rot < 0:
+                        rot = f32(rot + f32(360))
+                    b = rnd(float(f32(rot / f32(f32(360) * factor))))
+                    hist[0 if b == 30 else b].append(bidx)
+        if check_ori:
+            m1 = m2 = m3 = 0
+            i1 = i2 = i3 = -1
+            for i, h in enumerate(hist):
+                s = len(h)
+                if s > m1:
+                    m3, m2, m1, i3, i2, i1 = m2, m1, s, i2, i1, i
+                elif s > m2:
+                    m3, m2, i3, i2 = m2, s, i2, i
+                elif s > m3:
+                    m3, i3 = s, i
+            if m2 < f32(0.1) * f32(m1):
+                i2 = i3 = -1
+            elif m3 < f32(0.1) * f32(m1):
+                i3 = -1
+            for i in range(30):
+                if i not in (i1, i2, i3):
+                    for e in hist[i]:
+                        holder[e] = -1
+                        n -= 1
+        return n, np.array(holder, np.int32)
+
+    seen = 0
+    for th, mbf, direction, stereo, check_ori in ((15, 0.0, 0, False, True), (7, 40.0, 0, True, True),
+                                                  (14, 40.0, 1, True, False), (14, 40.0, 2, True, True),
+                                                  (40, 0.0, 0, False, False)):
+        want_n, want = restate(th, mbf, direction, stereo, check_ori)
+        got_n, got = orc.search_by_projection_frame(uv, inv_z, octs, ang, dm, has_obs, k2, d2, bounds, sf, th, mbf,
+                                                    direction, ur2 if stereo else None, occupied, check_ori)
+        assert got_n == want_n and np.array_equal(got, want), (th, direction, stereo, check_ori)
+        seen += max(want_n, 0)
+    assert seen > 100
