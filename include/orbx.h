@@ -271,6 +271,23 @@ int orbx_search_by_projection_frame(orbx_matcher* m, const float* proj_uv, const
                                     float mbf, int direction, int check_orientation, int32_t* matches,
                                     int* nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th) (src/ORBmatcher.cc:41-123;
+ * called from Tracking::SearchLocalPoints, src/Tracking.cc:1253-1263), host arrays in and out. The caller keeps
+ * Frame::isInFrustum (src/Frame.cc:293-363) and passes, for each of the npts map points that pass :51 (not bad,
+ * mbTrackInView) in vpMapPoints order: proj_xy = mTrackProjX / mTrackProjY, proj_xr = mTrackProjXR (read only when
+ * u_right is given), view_cos = mTrackViewCos, level = mnTrackScaleLevel, the descriptor and
+ * has_observations. Window radius RadiusByViewingCos(view_cos) [* th if th != 1] * scale_factors[level], levels
+ * level-1..level (:57-63), stereo bound (:85-90) and distances on the GPU; best / second best with their
+ * levels, TH_HIGH and the same-level ratio test (:96-119) on the host in vpMapPoints order. The other arguments
+ * and `matches` as in orbx_search_by_projection_frame. */
+int orbx_search_by_projection_points(orbx_matcher* m, const float* proj_xy, const float* proj_xr,
+                                     const float* view_cos, const int32_t* level, const uint8_t* desc_mp,
+                                     const uint8_t* has_observations, int npts, const orbx_keypoint* keys_un,
+                                     const uint8_t* desc, const float* u_right, const uint8_t* occupied, int n,
+                                     const int32_t* cell_start, const int32_t* cell_items, float min_x, float min_y,
+                                     float max_x, float max_y, const float* scale_factors, int nlevels, float th,
+                                     float nnratio, int32_t* matches, int* nmatches);
+
 /* ORBmatcher::SearchByBoW, host arrays in and out. mode ORBX_BOW_KEYFRAME_FRAME follows
  * SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:153-293): side 1 is the keyframe
  * (keys1_un = mvKeysUn, valid1[i] != 0 where the keyframe holds a live map point), side 2 the frame

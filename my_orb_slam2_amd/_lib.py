@@ -87,6 +87,9 @@ SIGNATURES = {
     "orbx_search_by_projection_frame": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P,
                                                   C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int, C.c_float,
                                                   C.c_float, C.c_int, C.c_int, _P, C.POINTER(C.c_int)]),
+    "orbx_search_by_projection_points": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P,
+                                                   C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int, C.c_float,
+                                                   C.c_float, _P, C.POINTER(C.c_int)]),
     "orbx_search_by_bow": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int,
                                      _P, _P, _P, C.c_int, C.c_float, C.c_int, _P, C.POINTER(C.c_int)]),
     "orbx_image_bounds": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -1191,3 +1191,51 @@ extern "C" int orbx_search_by_projection_frame(orbx_matcher* m, const float* pro
                                                   matches);
     return ORBX_OK;
 }
+
+extern "C" int orbx_search_by_projection_points(orbx_matcher* m, const float* proj_xy, const float* proj_xr,
+                                                const float* view_cos, const int32_t* level, const uint8_t* desc_mp,
+                                                const uint8_t* has_observations, int npts,
+                                                const orbx_keypoint* keys_un, const uint8_t* desc,
+                                                const float* u_right, const uint8_t* occupied, int n,
+                                                const int32_t* cell_start, const int32_t* cell_items, float min_x,
+                                                float min_y, float max_x, float max_y, const float* scale_factors,
+                                                int nlevels, float th, float nnratio, int32_t* matches,
+                                                int* nmatches) {
+    if (!m || npts < 0 || n < 0 || !nmatches || !(max_x > min_x) || !(max_y > min_y) || !scale_factors ||
+        nlevels < 1 || nlevels > ORBX_MAX_LEVELS ||
+        (npts > 0 && (!proj_xy || !view_cos || !level || !desc_mp || !has_observations || (u_right && !proj_xr))) ||
+        (n > 0 && (!keys_un || !desc || !cell_start || !cell_items || !matches))) {
+        set_error("orbx_search_by_projection_points: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    *nmatches = 0;
+    for (int i = 0; i < n; i++) matches[i] = -1;
+    if (npts == 0 || n == 0) return ORBX_OK;
+    const bool bFactor = th != 1.0;                                  // :45
+    std::vector<WindowQuery> queries(npts);
+    for (int i = 0; i < npts; i++) {
+        WindowQuery q{0.f, 0.f, -1.0f, 0.f, 0, -1};
+        const int lv = level[i];
+        if (lv >= 0 && lv < nlevels) {                               // (PredictScale never leaves the table)
+            float r = view_cos[i] > 0.998 ? 2.5 : 4.0;               // RadiusByViewingCos (:125-131)
+            if (bFactor) r *= th;                                    // :59-60
+            q.x = proj_xy[2 * i];
+            q.y = proj_xy[2 * i + 1];
+            q.r = r * scale_factors[lv];                             // :63, and the stereo bound of :88
+            q.ur = u_right ? proj_xr[i] : 0.f;
+            q.minLevel = lv - 1;
+            q.maxLevel = lv;
+            if (!(q.r >= 0.0f)) q.r = -1.0f;
+        }
+        queries[i] = q;
+    }
+    std::vector<int32_t> head;
+    int rc = run_window_search(m, "orbx_search_by_projection_points", queries, desc_mp, keys_un, desc, u_right, n,
+                               cell_start, cell_items, min_x, min_y, max_x, max_y, head);
+    if (rc) return rc;
+    *nmatches = replay_search_by_projection_points(npts, head.data() + 1, head.data() + 1 + npts,
+                                                   reinterpret_cast<const uint32_t*>(m->pin), has_observations,
+                                                   keys_un, occupied, n, nnratio, matches);
+    return ORBX_OK;
+}
+

@@ -189,6 +189,9 @@ int replay_search_by_projection_frame(int npts, const int32_t* candCount, const 
                                       const uint32_t* cand, const float* lastAngle, const uint8_t* hasObs,
                                       const orbx_keypoint* k2, const uint8_t* occupied2, int n2, bool checkOri,
                                       int32_t* match2);
+int replay_search_by_projection_points(int npts, const int32_t* candCount, const int32_t* candOffset,
+                                       const uint32_t* cand, const uint8_t* hasObs, const orbx_keypoint* k2,
+                                       const uint8_t* occupied2, int n2, float nnratio, int32_t* match2);
 int replay_search_for_initialization(const orbx_keypoint* k1, int n1, const orbx_keypoint* k2, int n2,
                                      const int32_t* candCount, const int32_t* candOffset, const uint32_t* cand,
                                      float* prev, float nnratio, bool checkOri, int32_t* matches12);

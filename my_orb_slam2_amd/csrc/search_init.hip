@@ -1,5 +1,6 @@
 // ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:413-530) and
-// ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (:1372-1516): the windowed searches over the
+// ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) (:1372-1516) and
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (:41-123): the windowed searches over the
 // current frame's 64 x 48 grid.
 //
 // The data-parallel part — Frame::GetFeaturesInArea (src/Frame.cc:365-418) for every level-0 keypoint of
@@ -283,6 +284,48 @@ int replay_search_by_projection_frame(int npts, const int32_t* candCount, const 
                 match2[idx2] = -1;
                 nmatches--;
             }
+        }
+    }
+    return nmatches;
+}
+
+// Host half of SearchByProjection(Frame&, const vector<MapPoint*>&, th): src/ORBmatcher.cc:70-119 over the
+// GPU-made candidate lists.
+int replay_search_by_projection_points(int npts, const int32_t* candCount, const int32_t* candOffset,
+                                       const uint32_t* cand, const uint8_t* hasObs, const orbx_keypoint* k2,
+                                       const uint8_t* occupied2, int n2, float nnratio, int32_t* match2) {
+    const int TH_HIGH = 100;
+    std::vector<uint8_t> blocked(n2, 0);
+    for (int i = 0; i < n2; i++) {
+        match2[i] = -1;
+        blocked[i] = occupied2 ? (occupied2[i] != 0) : 0;
+    }
+    int nmatches = 0;
+    for (int i = 0; i < npts; i++) {
+        const int nc = candCount[i];
+        if (nc == 0) continue;
+        const uint32_t* list = cand + candOffset[i];
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = (int)(list[c] & 0x7FFFFFu), dist = (int)(list[c] >> 23);
+            if (blocked[idx]) continue;
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = k2[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = k2[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            // ratio to the second match only when both sit on the same pyramid level (:114)
+            if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;
+            match2[bestIdx] = i;
+            blocked[bestIdx] = hasObs[i] != 0;
+            nmatches++;
         }
     }
     return nmatches;

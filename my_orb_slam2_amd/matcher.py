@@ -183,6 +183,40 @@ class HammingMatcher:
             "orbx_search_by_projection_frame")
         return n.value, out
 
+    def search_by_projection_points(self, proj_xy, view_cos, level, desc_mp, has_observations, keys_un, desc,
+                                    cell_start, cell_items, bounds, scale_factors, th=1.0, nnratio=0.8, proj_xr=None,
+                                    u_right=None, occupied=None):
+        """ORBmatcher::SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:41-123); Tracking::SearchLocalPoints
+        calls it with ORBmatcher(0.8) and th = 1, 3 or 5 (src/Tracking.cc:1253-1263). Host numpy arrays; see
+        include/orbx.h. Returns (nmatches, matches) with one entry per feature of F."""
+        from ._lib import KEYPOINT_DTYPE
+        xy = np.ascontiguousarray(proj_xy, dtype=np.float32).reshape(-1, 2)
+        vc = np.ascontiguousarray(view_cos, dtype=np.float32)
+        lv = np.ascontiguousarray(level, dtype=np.int32)
+        dm = np.ascontiguousarray(desc_mp, dtype=np.uint8).reshape(-1, 32)
+        ho = np.ascontiguousarray(has_observations, dtype=np.uint8)
+        k2 = np.ascontiguousarray(keys_un, dtype=KEYPOINT_DTYPE)
+        d2 = np.ascontiguousarray(desc, dtype=np.uint8)
+        cs = np.ascontiguousarray(cell_start, dtype=np.int32)
+        ci = np.ascontiguousarray(cell_items, dtype=np.int32)
+        sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+        xr = None if proj_xr is None else np.ascontiguousarray(proj_xr, dtype=np.float32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, dtype=np.float32)
+        oc = None if occupied is None else np.ascontiguousarray(occupied, dtype=np.uint8)
+        npts = len(xy)
+        assert len(vc) == npts and len(lv) == npts and len(dm) == npts and len(ho) == npts
+        assert (ur is None or (len(ur) == len(k2) and xr is not None and len(xr) == npts))
+        assert oc is None or len(oc) == len(k2)
+        out = np.empty(len(k2), dtype=np.int32)
+        n = C.c_int(0)
+        check(lib().orbx_search_by_projection_points(
+            self._m, np_ptr(xy), None if xr is None else np_ptr(xr), np_ptr(vc), np_ptr(lv), np_ptr(dm), np_ptr(ho),
+            npts, np_ptr(k2), np_ptr(d2), None if ur is None else np_ptr(ur), None if oc is None else np_ptr(oc),
+            len(k2), np_ptr(cs), np_ptr(ci), float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]),
+            np_ptr(sf), len(sf), float(th), float(nnratio), np_ptr(out), C.byref(n)),
+            "orbx_search_by_projection_points")
+        return n.value, out
+
     def search_by_bow(self, keys1_un, desc1, valid1, fv1, keys2, desc2, fv2, valid2=None, nnratio=0.7,
                       check_orientation=True):
         """ORBmatcher::SearchByBoW. valid2 None: the KeyFrame x Frame overload (src/ORBmatcher.cc:153-293,

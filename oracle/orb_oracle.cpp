@@ -1271,3 +1271,88 @@ extern "C" int orc_search_by_projection_frame(const float* uv, const float* invz
     return nmatches;
 }
 
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), src/ORBmatcher.cc:41-123 */
+extern "C" int orc_search_by_projection_points(const float* proj, const float* proj_xr, const float* view_cos,
+                                               const int32_t* level, const uint8_t* desc_mp,
+                                               const uint8_t* has_obs, int npts, const orc_keypoint* k2,
+                                               const uint8_t* d2, const float* uright2, const uint8_t* occupied2,
+                                               int n2, float minX, float minY, float maxX, float maxY,
+                                               const float* scale_factors, int nlevels, float th, float mfNNratio,
+                                               int32_t* match2) {
+    const int COLS = 64, ROWS = 48, TH_HIGH = 100;
+    const float invW = static_cast<float>(COLS) / (maxX - minX), invH = static_cast<float>(ROWS) / (maxY - minY);
+    std::vector<std::vector<uint32_t>> grid(COLS * ROWS);
+    for (int i = 0; i < n2; i++) {
+        const int posX = (int)std::round((k2[i].x - minX) * invW), posY = (int)std::round((k2[i].y - minY) * invH);
+        if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+        grid[posX * ROWS + posY].push_back((uint32_t)i);
+    }
+    auto features_in_area = [&](float x, float y, float r, int minLevel, int maxLevel) {   /* src/Frame.cc:365-418 */
+        std::vector<size_t> v;
+        const int nMinCellX = std::max(0, (int)std::floor((x - minX - r) * invW));
+        if (nMinCellX >= COLS) return v;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x - minX + r) * invW));
+        if (nMaxCellX < 0) return v;
+        const int nMinCellY = std::max(0, (int)std::floor((y - minY - r) * invH));
+        if (nMinCellY >= ROWS) return v;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y - minY + r) * invH));
+        if (nMaxCellY < 0) return v;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (uint32_t j : grid[ix * ROWS + iy]) {
+                    const orc_keypoint& kp = k2[j];
+                    if (bCheckLevels) {
+                        if (kp.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                    }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) v.push_back(j);
+                }
+        return v;
+    };
+    std::vector<int32_t> holder(n2, -1);
+    std::vector<uint8_t> blocked(n2, 0);
+    for (int i = 0; i < n2; i++) blocked[i] = occupied2 ? (occupied2[i] != 0) : 0;
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < npts; iMP++) {
+        const int nPredictedLevel = level[iMP];
+        if (nPredictedLevel < 0 || nPredictedLevel >= nlevels) continue;    /* (not a value PredictScale returns) */
+        float r = view_cos[iMP] > 0.998 ? 2.5 : 4.0;                        /* RadiusByViewingCos (:125-131) */
+        if (bFactor) r *= th;
+        const std::vector<size_t> vIndices = features_in_area(proj[2 * iMP], proj[2 * iMP + 1],
+                                                              r * scale_factors[nPredictedLevel],
+                                                              nPredictedLevel - 1, nPredictedLevel);
+        if (vIndices.empty()) continue;
+        const uint8_t* MPdescriptor = desc_mp + 32 * (size_t)iMP;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t idx : vIndices) {
+            if (blocked[idx]) continue;
+            if (uright2 && uright2[idx] > 0) {
+                const float er = std::fabs(proj_xr[iMP] - uright2[idx]);
+                if (er > r * scale_factors[nPredictedLevel]) continue;
+            }
+            const int dist = orc_hamming256(MPdescriptor, d2 + 32 * idx);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = k2[idx].octave;
+                bestIdx = (int)idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = k2[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+            holder[bestIdx] = iMP;
+            blocked[bestIdx] = has_obs[iMP] != 0;
+            nmatches++;
+        }
+    }
+    for (int i = 0; i < n2; i++) match2[i] = holder[i];
+    return nmatches;
+}
+

@@ -152,6 +152,17 @@ int   orc_search_by_projection_frame(const float* uv, const float* invz, const i
                                      float maxY, const float* scale_factors, int nlevels, float th, float mbf,
                                      int direction, int check_orientation, int32_t* match2);
 
+/* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th) (src/ORBmatcher.cc:41-123)
+ * for the npts map points that pass :51 (not bad, mbTrackInView), in vpMapPoints order: proj[2i], proj[2i+1] =
+ * mTrackProjX/Y, proj_xr = mTrackProjXR, view_cos = mTrackViewCos, level = mnTrackScaleLevel. The other arguments
+ * and match2 as in orc_search_by_projection_frame. Returns nmatches. */
+int   orc_search_by_projection_points(const float* proj, const float* proj_xr, const float* view_cos,
+                                      const int32_t* level, const uint8_t* desc_mp, const uint8_t* has_obs, int npts,
+                                      const orc_keypoint* k2, const uint8_t* d2, const float* uright2,
+                                      const uint8_t* occupied2, int n2, float minX, float minY, float maxX,
+                                      float maxY, const float* scale_factors, int nlevels, float th,
+                                      float nnratio, int32_t* match2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,10 @@ def lib():
         L.orc_search_by_projection_frame.argtypes = [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int,
                                                      C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int,
                                                      C.c_float, C.c_float, C.c_int, C.c_int, _P]
+        L.orc_search_by_projection_points.restype = C.c_int
+        L.orc_search_by_projection_points.argtypes = [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int,
+                                                      C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int,
+                                                      C.c_float, C.c_float, _P]
         _LIB = L
     return _LIB
 
@@ -303,5 +307,26 @@ def search_by_projection_frame(uv, inv_z, last_octave, last_angle, desc_mp, has_
                                              None if oc is None else ptr(oc), len(k2), bounds[0], bounds[1],
                                              bounds[2], bounds[3], ptr(sf), len(sf), th, mbf, direction,
                                              1 if check_ori else 0, ptr(out))
+    return n, out
+
+
+def search_by_projection_points(proj_xy, view_cos, level, desc_mp, has_obs, k2, d2, bounds, scale_factors, th=1.0,
+                                nnratio=0.8, proj_xr=None, u_right=None, occupied=None):
+    xy = np.ascontiguousarray(proj_xy, dtype=np.float32).reshape(-1, 2)
+    vc = np.ascontiguousarray(view_cos, dtype=np.float32)
+    lv = np.ascontiguousarray(level, dtype=np.int32)
+    dm = np.ascontiguousarray(desc_mp, dtype=np.uint8).reshape(-1, 32)
+    ho = np.ascontiguousarray(has_obs, dtype=np.uint8)
+    k2 = np.ascontiguousarray(k2, dtype=KP)
+    d2 = np.ascontiguousarray(d2, dtype=np.uint8)
+    sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+    xr = np.zeros(len(xy), np.float32) if proj_xr is None else np.ascontiguousarray(proj_xr, dtype=np.float32)
+    ur = None if u_right is None else np.ascontiguousarray(u_right, dtype=np.float32)
+    oc = None if occupied is None else np.ascontiguousarray(occupied, dtype=np.uint8)
+    out = np.empty(len(k2), dtype=np.int32)
+    n = lib().orc_search_by_projection_points(ptr(xy), ptr(xr), ptr(vc), ptr(lv), ptr(dm), ptr(ho), len(xy), ptr(k2),
+                                              ptr(d2), None if ur is None else ptr(ur),
+                                              None if oc is None else ptr(oc), len(k2), bounds[0], bounds[1],
+                                              bounds[2], bounds[3], ptr(sf), len(sf), th, nnratio, ptr(out))
     return n, out
 

@@ -72,6 +72,29 @@ def test_search_by_projection_frame(seed, th, direction, stereo):
     run_both(c, occupied=False)
 
 
+@pytest.mark.parametrize("seed,th,ratio,stereo", [(11, 1.0, 0.8, False), (12, 3.0, 0.8, True), (13, 5.0, 0.8, True),
+                                                   (14, 1.0, 0.6, True)])
+def test_search_by_projection_points(seed, th, ratio, stereo):
+    """The local-map overload (src/ORBmatcher.cc:41-123): radius from the viewing angle, levels l-1..l, ratio test
+    only between candidates of one level."""
+    c = make_case(seed, 15, 0, stereo)
+    rng = np.random.default_rng(seed)
+    npts = len(c["uv"])
+    view_cos = rng.uniform(0.99, 1.0, npts).astype(np.float32)
+    level = np.clip(c["last_octave"] + rng.integers(-1, 2, npts), 0, 7).astype(np.int32)
+    uv = (c["uv"] + rng.normal(0, 1.0, (npts, 2))).astype(np.float32)
+    xr = (uv[:, 0] - rng.uniform(0, 40, npts)).astype(np.float32) if stereo else None
+    hm = m.HammingMatcher()
+    for occ in (c["occupied"], None):
+        want = orc.search_by_projection_points(uv, view_cos, level, c["desc_mp"], c["has_obs"], c["kc"], c["dc"], BOUNDS,
+                                               c["sf"], th, ratio, xr, c["u_right"], occ)
+        got = hm.search_by_projection_points(uv, view_cos, level, c["desc_mp"], c["has_obs"], c["kc"], c["dc"],
+                                             c["start"], c["items"], BOUNDS, c["sf"], th, ratio, xr, c["u_right"], occ)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    if th >= 3:
+        assert got[0] > 20
+
+
 def test_search_by_projection_frame_edges():
     c = make_case(7, 15, 0, False, nfeatures=300)
     hm = m.HammingMatcher()

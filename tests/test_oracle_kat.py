@@ -538,6 +538,48 @@ def test_search_by_projection_against_python_restatement():
                         n -= 1
         return n, np.array(holder, np.int32)
 
+    # --- the map-point overload (src/ORBmatcher.cc:41-123) on the same data ---
+    view_cos = rng.uniform(0.99, 1.0, npts).astype(f32)
+    xr = (uv[:, 0] - rng.uniform(0, 30, npts)).astype(f32)
+
+    def restate_points(th, ratio, stereo):
+        holder = [-1] * n2
+        blocked = [bool(b) for b in occupied]
+        n = 0
+        for i in range(npts):
+            o = int(octs[i])
+            r = f32(2.5) if float(view_cos[i]) > 0.998 else f32(4.0)
+            if th != 1.0:
+                r = f32(r * f32(th))
+            radius = f32(r * sf[o])
+            b1, l1, b2, l2, bi = 256, -1, 256, -1, -1
+            for j in area(uv[i, 0], uv[i, 1], radius, o - 1, o):
+                if blocked[j]:
+                    continue
+                if stereo and ur2[j] > 0 and abs(f32(xr[i] - ur2[j])) > radius:
+                    continue
+                dist = ham(dm[i], d2[j])
+                if dist < b1:
+                    b2, b1, l2, l1, bi = b1, dist, l1, int(k2["octave"][j]), j
+                elif dist < b2:
+                    l2, b2 = int(k2["octave"][j]), dist
+            if b1 <= 100:
+                if l1 == l2 and f32(b1) > f32(f32(ratio) * f32(b2)):
+                    continue
+                holder[bi] = i
+                blocked[bi] = bool(has_obs[i])
+                n += 1
+        return n, np.array(holder, np.int32)
+
+    seen_pts = 0
+    for th, ratio, stereo in ((1.0, 0.8, False), (3.0, 0.8, True), (5.0, 0.6, True)):
+        want_n, want = restate_points(th, ratio, stereo)
+        got_n, got = orc.search_by_projection_points(uv, view_cos, octs, dm, has_obs, k2, d2, bounds, sf, th, ratio,
+                                                     xr if stereo else None, ur2 if stereo else None, occupied)
+        assert got_n == want_n and np.array_equal(got, want), (th, ratio, stereo)
+        seen_pts += want_n
+    assert seen_pts > 60
+
     seen = 0
     for th, mbf, direction, stereo, check_ori in ((15, 0.0, 0, False, True), (7, 40.0, 0, True, True),
                                                   (14, 40.0, 1, True, False), (14, 40.0, 2, True, True),
