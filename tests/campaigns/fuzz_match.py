@@ -30,7 +30,7 @@ def main():
     from tests import oracle as orc
     rng = np.random.default_rng(a.seed)
     hm = m.HammingMatcher()
-    done = {"knn": 0, "stereo_pairs": 0, "stereo_matches": 0, "grid_frames": 0, "init_matches": 0, "projection_matches": 0}
+    done = {"knn": 0, "stereo_pairs": 0, "stereo_matches": 0, "grid_frames": 0, "init_matches": 0, "projection_matches": 0, "local_map_matches": 0}
 
     for case in range(a.cases):
         # ---- kNN ----
@@ -173,6 +173,17 @@ def main():
                 fail("search_by_projection_frame", dict(case=case, w=w, h=h, nf=nf, idx=idx0, th=th, direction=direction,
                                                         stereo=stereo, ori=ori, n=n, want_n=want_n))
             done["projection_matches"] += n
+            # the local-map overload on the same data
+            vcos = rng.uniform(0.99, 1.0, npts).astype(np.float32)
+            lvl = np.clip(k1["octave"][pick] + rng.integers(-1, 2, npts), 0, 7).astype(np.int32)
+            xr = (uv[:, 0] - rng.uniform(0, 40, npts)).astype(np.float32) if stereo else None
+            th2 = float(rng.choice([1.0, 3.0, 5.0]))
+            want_n, want = orc.search_by_projection_points(uv, vcos, lvl, dmp, has_obs, k2, d2, ib, sfac, th2, ratio, xr, ur2, occ)
+            n, got = hm.search_by_projection_points(uv, vcos, lvl, dmp, has_obs, k2, d2, s2,
+                                                    i2 if len(i2) else np.zeros(1, np.int32), ib, sfac, th2, ratio, xr, ur2, occ)
+            if n != want_n or not np.array_equal(got, want):
+                fail("search_by_projection_points", dict(case=case, w=w, h=h, nf=nf, idx=idx0, th=th2, ratio=ratio, stereo=stereo))
+            done["local_map_matches"] += n
         exl.close()
         exr.close()
     print(json.dumps(dict(cases=a.cases, seed=a.seed, differences=0, **done)))
