@@ -259,16 +259,21 @@ int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* keys1_u
  * cell_items its grid. The frustum and image-bound tests (:1411-1420), the search radius th * scale_factors[o]
  * (:1425), Frame::GetFeaturesInArea, the stereo consistency test (:1451-1457) and all distances run on the
  * GPU in the reference's visiting order; the order-dependent part (what a feature already holds, best distance
- * <= TH_HIGH, rotation histogram) runs on the host as written there. matches receives, per current-frame
- * feature, the index into the npts list of the map point assigned to it (-1 = none); *nmatches the return
- * value. */
+ * <= max_dist, rotation histogram) runs on the host as written there. max_dist is TH_HIGH = 100 for this
+ * overload (:1470). matches receives, per current-frame feature, the index into the npts list of the map point
+ * assigned to it (-1 = none); *nmatches the return value.
+ * The relocalisation overload SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (:1518-1650,
+ * src/Tracking.cc:1501,1515) is the same loop: pass the points that survive :1541-1570 with last_octave = the
+ * predicted level, last_angle = pKF->mvKeysUn[i].angle, inv_z = any positive value (that overload has no test on
+ * it), has_observations all 1, occupied[i] = (mvpMapPoints[i] != nullptr), u_right NULL, direction 0 and
+ * max_dist = ORBdist. */
 int orbx_search_by_projection_frame(orbx_matcher* m, const float* proj_uv, const float* inv_z,
                                     const int32_t* last_octave, const float* last_angle, const uint8_t* desc_mp,
                                     const uint8_t* has_observations, int npts, const orbx_keypoint* keys_un,
                                     const uint8_t* desc, const float* u_right, const uint8_t* occupied, int n,
                                     const int32_t* cell_start, const int32_t* cell_items, float min_x, float min_y,
                                     float max_x, float max_y, const float* scale_factors, int nlevels, float th,
-                                    float mbf, int direction, int check_orientation, int32_t* matches,
+                                    float mbf, int direction, int max_dist, int check_orientation, int32_t* matches,
                                     int* nmatches);
 
 /* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th) (src/ORBmatcher.cc:41-123;
@@ -279,7 +284,7 @@ int orbx_search_by_projection_frame(orbx_matcher* m, const float* proj_uv, const
  * has_observations. Window radius RadiusByViewingCos(view_cos) [* th if th != 1] * scale_factors[level], levels
  * level-1..level (:57-63), stereo bound (:85-90) and distances on the GPU; best / second best with their
  * levels, TH_HIGH and the same-level ratio test (:96-119) on the host in vpMapPoints order. The other arguments
- * and `matches` as in orbx_search_by_projection_frame. */
+ * and `matches` as in orbx_search_by_projection_frame (the threshold is TH_HIGH, :112). */
 int orbx_search_by_projection_points(orbx_matcher* m, const float* proj_xy, const float* proj_xr,
                                      const float* view_cos, const int32_t* level, const uint8_t* desc_mp,
                                      const uint8_t* has_observations, int npts, const orbx_keypoint* keys_un,

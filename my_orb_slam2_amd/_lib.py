@@ -86,7 +86,7 @@ SIGNATURES = {
                                                  C.POINTER(C.c_int)]),
     "orbx_search_by_projection_frame": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P,
                                                   C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int, C.c_float,
-                                                  C.c_float, C.c_int, C.c_int, _P, C.POINTER(C.c_int)]),
+                                                  C.c_float, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_int)]),
     "orbx_search_by_projection_points": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P,
                                                    C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int, C.c_float,
                                                    C.c_float, _P, C.POINTER(C.c_int)]),

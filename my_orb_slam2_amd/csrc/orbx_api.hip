@@ -1151,7 +1151,7 @@ extern "C" int orbx_search_by_projection_frame(orbx_matcher* m, const float* pro
                                                const float* u_right, const uint8_t* occupied, int n,
                                                const int32_t* cell_start, const int32_t* cell_items, float min_x,
                                                float min_y, float max_x, float max_y, const float* scale_factors,
-                                               int nlevels, float th, float mbf, int direction,
+                                               int nlevels, float th, float mbf, int direction, int max_dist,
                                                int check_orientation, int32_t* matches, int* nmatches) {
     if (!m || npts < 0 || n < 0 || !nmatches || !(max_x > min_x) || !(max_y > min_y) || !scale_factors ||
         nlevels < 1 || nlevels > ORBX_MAX_LEVELS || direction < 0 || direction > 2 ||
@@ -1187,8 +1187,8 @@ extern "C" int orbx_search_by_projection_frame(orbx_matcher* m, const float* pro
     if (rc) return rc;
     *nmatches = replay_search_by_projection_frame(npts, head.data() + 1, head.data() + 1 + npts,
                                                   reinterpret_cast<const uint32_t*>(m->pin), last_angle,
-                                                  has_observations, keys_un, occupied, n, check_orientation != 0,
-                                                  matches);
+                                                  has_observations, keys_un, occupied, n, max_dist,
+                                                  check_orientation != 0, matches);
     return ORBX_OK;
 }
 

@@ -187,8 +187,8 @@ hipError_t launch_window_candidates(int n1, const WindowQuery* queries, const ui
                                     uint32_t* cand, hipStream_t s);
 int replay_search_by_projection_frame(int npts, const int32_t* candCount, const int32_t* candOffset,
                                       const uint32_t* cand, const float* lastAngle, const uint8_t* hasObs,
-                                      const orbx_keypoint* k2, const uint8_t* occupied2, int n2, bool checkOri,
-                                      int32_t* match2);
+                                      const orbx_keypoint* k2, const uint8_t* occupied2, int n2, int maxDist,
+                                      bool checkOri, int32_t* match2);
 int replay_search_by_projection_points(int npts, const int32_t* candCount, const int32_t* candOffset,
                                        const uint32_t* cand, const uint8_t* hasObs, const orbx_keypoint* k2,
                                        const uint8_t* occupied2, int n2, float nnratio, int32_t* match2);

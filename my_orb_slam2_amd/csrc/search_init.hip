@@ -238,9 +238,9 @@ hipError_t launch_window_candidates(int n1, const WindowQuery* queries, const ui
 // changes as the loop goes, so the best match of a map point depends on the points before it.
 int replay_search_by_projection_frame(int npts, const int32_t* candCount, const int32_t* candOffset,
                                       const uint32_t* cand, const float* lastAngle, const uint8_t* hasObs,
-                                      const orbx_keypoint* k2, const uint8_t* occupied2, int n2, bool checkOri,
-                                      int32_t* match2) {
-    const int HISTO_LENGTH = 30, TH_HIGH = 100;   // include/PresetParameters.h:11-13
+                                      const orbx_keypoint* k2, const uint8_t* occupied2, int n2, int maxDist,
+                                      bool checkOri, int32_t* match2) {
+    const int HISTO_LENGTH = 30;                  // include/PresetParameters.h:11-13
     std::vector<uint8_t> blocked(n2, 0);          // mvpMapPoints[i2] && mvpMapPoints[i2]->Observations() > 0
     for (int i = 0; i < n2; i++) {
         match2[i] = -1;
@@ -262,7 +262,7 @@ int replay_search_by_projection_frame(int npts, const int32_t* candCount, const 
                 bestIdx2 = i2;
             }
         }
-        if (bestDist <= TH_HIGH) {
+        if (bestDist <= maxDist) {                // TH_HIGH (:1470) or ORBdist (:1604)
             match2[bestIdx2] = i;
             blocked[bestIdx2] = hasObs[i] != 0;
             nmatches++;

@@ -150,11 +150,12 @@ class HammingMatcher:
 
     def search_by_projection_frame(self, proj_uv, inv_z, last_octave, last_angle, desc_mp, has_observations,
                                    keys_un, desc, cell_start, cell_items, bounds, scale_factors, th, mbf=0.0,
-                                   direction=0, u_right=None, occupied=None, check_orientation=True):
+                                   direction=0, u_right=None, occupied=None, check_orientation=True, max_dist=100):
         """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1372-1516) from the
         projection onwards; Tracking calls it with ORBmatcher(0.9, true) and th = 15 (7 for stereo), then 2 * th
         (src/Tracking.cc:929-940). Host numpy arrays; see include/orbx.h for the meaning of every argument.
-        Returns (nmatches, matches) with one entry per current-frame feature."""
+        max_dist = 100 (TH_HIGH) for that overload; the relocalisation overload (:1518-1650) is the same call with
+        max_dist = ORBdist (see include/orbx.h). Returns (nmatches, matches) with one entry per current-frame feature."""
         from ._lib import KEYPOINT_DTYPE
         uv = np.ascontiguousarray(proj_uv, dtype=np.float32).reshape(-1, 2)
         iz = np.ascontiguousarray(inv_z, dtype=np.float32)
@@ -179,8 +180,8 @@ class HammingMatcher:
             self._m, np_ptr(uv), np_ptr(iz), np_ptr(lo), np_ptr(la), np_ptr(dm), np_ptr(ho), npts, np_ptr(k2),
             np_ptr(d2), None if ur is None else np_ptr(ur), None if oc is None else np_ptr(oc), len(k2), np_ptr(cs),
             np_ptr(ci), float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), np_ptr(sf), len(sf),
-            float(th), float(mbf), int(direction), 1 if check_orientation else 0, np_ptr(out), C.byref(n)),
-            "orbx_search_by_projection_frame")
+            float(th), float(mbf), int(direction), int(max_dist), 1 if check_orientation else 0, np_ptr(out),
+            C.byref(n)), "orbx_search_by_projection_frame")
         return n.value, out
 
     def search_by_projection_points(self, proj_xy, view_cos, level, desc_mp, has_observations, keys_un, desc,

@@ -1165,8 +1165,8 @@ extern "C" int orc_search_by_projection_frame(const float* uv, const float* invz
                                               const uint8_t* d2, const float* uright2, const uint8_t* occupied2,
                                               int n2, float minX, float minY, float maxX, float maxY,
                                               const float* scale_factors, int nlevels, float th, float mbf,
-                                              int direction, int checkOri, int32_t* match2) {
-    const int COLS = 64, ROWS = 48, HISTO_LENGTH = 30, TH_HIGH = 100;
+                                              int direction, int maxDist, int checkOri, int32_t* match2) {
+    const int COLS = 64, ROWS = 48, HISTO_LENGTH = 30;
     const float invW = static_cast<float>(COLS) / (maxX - minX), invH = static_cast<float>(ROWS) / (maxY - minY);
     std::vector<std::vector<uint32_t>> grid(COLS * ROWS);   /* mGrid of the current frame (src/Frame.cc:268-283) */
     for (int i = 0; i < n2; i++) {
@@ -1236,7 +1236,7 @@ extern "C" int orc_search_by_projection_frame(const float* uv, const float* invz
                 bestIdx2 = (int)i2;
             }
         }
-        if (bestDist <= TH_HIGH) {
+        if (bestDist <= maxDist) {                                          /* TH_HIGH :1470, ORBdist :1604 */
             holder[bestIdx2] = i;                                           /* :1472 */
             blocked[bestIdx2] = has_obs[i] != 0;
             nmatches++;

@@ -144,13 +144,17 @@ int   orc_search_by_bow(int mode, const orc_keypoint* k1, const uint8_t* d1, con
  * (levels o-1..o+1), 1 = bForward (levels >= o), 2 = bBackward (levels <= o) (:1392-1393, :1429-1434).
  * uright2 NULL = monocular (mvuRight all -1); occupied2[i] != 0 where CurrentFrame.mvpMapPoints[i] already
  * holds a point with observations (NULL = none). match2[i] receives the index (into the npts list) of the
- * map point assigned to current feature i, or -1. Returns nmatches. */
+ * map point assigned to current feature i, or -1. Returns nmatches. max_dist = TH_HIGH (100) for this overload.
+ * SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (:1518-1650) is the same loop with
+ * max_dist = ORBdist, no stereo test, levels l-1..l+1 around the predicted level (passed as last_octave), no
+ * test on invzc (pass any positive value), every feature that holds a point blocked (occupied2) and every
+ * assignment blocking (has_obs all 1). */
 int   orc_search_by_projection_frame(const float* uv, const float* invz, const int32_t* last_octave,
                                      const float* last_angle, const uint8_t* desc_mp, const uint8_t* has_obs,
                                      int npts, const orc_keypoint* k2, const uint8_t* d2, const float* uright2,
                                      const uint8_t* occupied2, int n2, float minX, float minY, float maxX,
                                      float maxY, const float* scale_factors, int nlevels, float th, float mbf,
-                                     int direction, int check_orientation, int32_t* match2);
+                                     int direction, int max_dist, int check_orientation, int32_t* match2);
 
 /* ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th) (src/ORBmatcher.cc:41-123)
  * for the npts map points that pass :51 (not bad, mbTrackInView), in vpMapPoints order: proj[2i], proj[2i+1] =

@@ -84,7 +84,7 @@ def lib():
         L.orc_search_by_projection_frame.restype = C.c_int
         L.orc_search_by_projection_frame.argtypes = [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int,
                                                      C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int,
-                                                     C.c_float, C.c_float, C.c_int, C.c_int, _P]
+                                                     C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _P]
         L.orc_search_by_projection_points.restype = C.c_int
         L.orc_search_by_projection_points.argtypes = [_P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int,
                                                       C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int,
@@ -289,7 +289,7 @@ def search_by_bow(k1, d1, valid1, fv1, k2, d2, fv2, valid2=None, nnratio=0.7, ch
 
 
 def search_by_projection_frame(uv, inv_z, last_octave, last_angle, desc_mp, has_obs, k2, d2, bounds, scale_factors,
-                               th, mbf=0.0, direction=0, u_right=None, occupied=None, check_ori=True):
+                               th, mbf=0.0, direction=0, u_right=None, occupied=None, check_ori=True, max_dist=100):
     uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
     iz = np.ascontiguousarray(inv_z, dtype=np.float32)
     lo = np.ascontiguousarray(last_octave, dtype=np.int32)
@@ -305,7 +305,7 @@ def search_by_projection_frame(uv, inv_z, last_octave, last_angle, desc_mp, has_
     n = lib().orc_search_by_projection_frame(ptr(uv), ptr(iz), ptr(lo), ptr(la), ptr(dm), ptr(ho), len(uv), ptr(k2),
                                              ptr(d2), None if ur is None else ptr(ur),
                                              None if oc is None else ptr(oc), len(k2), bounds[0], bounds[1],
-                                             bounds[2], bounds[3], ptr(sf), len(sf), th, mbf, direction,
+                                             bounds[2], bounds[3], ptr(sf), len(sf), th, mbf, direction, max_dist,
                                              1 if check_ori else 0, ptr(out))
     return n, out
 

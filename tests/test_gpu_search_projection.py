@@ -95,6 +95,25 @@ def test_search_by_projection_points(seed, th, ratio, stereo):
         assert got[0] > 20
 
 
+def test_relocalisation_overload_through_the_same_entry():
+    """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1518-1650): threshold
+    ORBdist, every held feature blocked, every assignment blocking, no test on invzc, no stereo test."""
+    c = make_case(21, 10, 0, False)
+    hm = m.HammingMatcher()
+    npts = len(c["uv"])
+    ones = np.ones(npts, np.uint8)
+    invz = np.ones(npts, np.float32)
+    for th, orb_dist in ((10, 100), (3, 64)):
+        want = orc.search_by_projection_frame(c["uv"], invz, c["last_octave"], c["last_angle"], c["desc_mp"], ones,
+                                              c["kc"], c["dc"], BOUNDS, c["sf"], th, 0.0, 0, None, c["occupied"], True,
+                                              orb_dist)
+        got = hm.search_by_projection_frame(c["uv"], invz, c["last_octave"], c["last_angle"], c["desc_mp"], ones,
+                                            c["kc"], c["dc"], c["start"], c["items"], BOUNDS, c["sf"], th, 0.0, 0, None,
+                                            c["occupied"], True, orb_dist)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    assert got[0] > 10
+
+
 def test_search_by_projection_frame_edges():
     c = make_case(7, 15, 0, False, nfeatures=300)
     hm = m.HammingMatcher()

@@ -482,7 +482,7 @@ def test_search_by_projection_against_python_restatement():
                         out.append(j)
         return out
 
-    def restate(th, mbf, direction, stereo, check_ori):
+    def restate(th, mbf, direction, stereo, check_ori, max_dist=100):
         holder = [-1] * n2
         blocked = [bool(b) for b in occupied]
         hist = [[] for _ in range(30)]
@@ -506,7 +506,7 @@ def test_search_by_projection_against_python_restatement():
                 dist = ham(dm[i], d2[j])
                 if dist < best:
                     best, bidx = dist, j
-            if best <= 100:
+            if best <= max_dist:
                 holder[bidx] = i
                 blocked[bidx] = bool(has_obs[i])
                 n += 1
@@ -581,12 +581,12 @@ def test_search_by_projection_against_python_restatement():
     assert seen_pts > 60
 
     seen = 0
-    for th, mbf, direction, stereo, check_ori in ((15, 0.0, 0, False, True), (7, 40.0, 0, True, True),
-                                                  (14, 40.0, 1, True, False), (14, 40.0, 2, True, True),
-                                                  (40, 0.0, 0, False, False)):
-        want_n, want = restate(th, mbf, direction, stereo, check_ori)
+    for th, mbf, direction, stereo, check_ori, md in ((15, 0.0, 0, False, True, 100), (7, 40.0, 0, True, True, 100),
+                                                      (14, 40.0, 1, True, False, 100), (14, 40.0, 2, True, True, 100),
+                                                      (40, 0.0, 0, False, False, 100), (10, 0.0, 0, False, True, 64)):
+        want_n, want = restate(th, mbf, direction, stereo, check_ori, md)
         got_n, got = orc.search_by_projection_frame(uv, inv_z, octs, ang, dm, has_obs, k2, d2, bounds, sf, th, mbf,
-                                                    direction, ur2 if stereo else None, occupied, check_ori)
+                                                    direction, ur2 if stereo else None, occupied, check_ori, md)
         assert got_n == want_n and np.array_equal(got, want), (th, direction, stereo, check_ori)
         seen += max(want_n, 0)
     assert seen > 100
