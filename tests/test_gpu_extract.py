@@ -362,3 +362,15 @@ def test_cpp_shim_program():
     assert (int(mt.group(8)), int(mt.group(9))) == cpu.level_size(1)
     assert int(mt.group(10)) == int(cpu.level_image(1)[0, 0])
     assert int(mt.group(11)) == orc.hamming(d[0], d[1])
+
+
+def test_cpp_api_walk_program():
+    """tests/cpp/api_walk.cpp calls every host-array entry point from plain C++ with odd sizes, strides, empty
+    inputs and malformed indices (the same program runs under host AddressSanitizer by tests/cpp/run_host_asan.sh)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "api_walk")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "api walk ok" in out.stdout
