@@ -162,15 +162,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Native libraries write to file descriptor 1 on their own (RCCL prints a version banner when its first
+    # communicator comes up): until the result line, everything that goes to fd 1 is sent to stderr instead.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
     torch.cuda.set_device(local)
     # ORBX_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (rehearsal on a one-GPU box)
     use_dist = world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     B = a.batch
     unique = max(B, (a.unique + B - 1) // B * B)
 
@@ -183,6 +184,12 @@ def main():
            for _ in range(nctx)]
     ex = exs[0]
     cap = ex.capacity
+    # The process group comes up after the extractor contexts: their streams are created first and get hardware
+    # queues of their own (the box runs four per process); RCCL's streams, idle during the timed region, share.
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     outs = [(torch.empty((B, cap, 7), dtype=torch.float32, device="cuda"),
              torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda"),
              torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(nctx)]
@@ -274,8 +281,11 @@ def main():
     if world == 1 and not a.no_hamming:
         h = hamming_bench(torch, local)
         out["hamming"] = {k: (round(v, 4) if isinstance(v, float) and v < 1e6 else v) for k, v in h.items()}
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
     if use_dist:
+        os.dup2(2, 1)
         dist.destroy_process_group()
 
 

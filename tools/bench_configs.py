@@ -52,8 +52,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def ensure_dist():
+        # The process group comes up after a workload has created its contexts: their streams get hardware queues
+        # of their own (four per process on the box), RCCL's idle streams share.
+        if world > 1 and not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     if "stereo" in which:
         B, W, H, NF, SETS = 128, 752, 480, 1200, 2          # two sets of (left, right, matcher) in flight
@@ -81,6 +85,7 @@ def main():
             # no host synchronisation: the call orders the three streams on the device (events)
             s["hm"].compute_stereo_matches_device(s["exl"], s["exr"], *s["L"], *s["R"], bf, b, s["ur"], s["z"])
         steps = 48
+        ensure_dist()
         dt = timed(torch, dist, world, step, steps, 6)
         for s in sets:
             s["hm"].synchronize()
@@ -105,6 +110,7 @@ def main():
             k, d, c = outs[i % NCTX]
             ex[i % NCTX].extract_batch_device(frames, k, d, c)
         steps = 48
+        ensure_dist()
         dt = timed(torch, dist, world, step, steps, 6)
         if rank == 0:
             print(json.dumps({"workload": "configs[3] 1920x1080, nFeatures 2000, 8 levels", "n_gpus": world,
@@ -121,6 +127,7 @@ def main():
         gq = torch.Generator(device="cuda").manual_seed(99)      # the same queries on every rank
         q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device="cuda", generator=gq)
         sm = ShardedHammingMatcher(db, rank * shard, device=local)
+        ensure_dist()
         res = []
 
         def step(i):
@@ -133,7 +140,7 @@ def main():
                               "value": nq * world * shard * steps / dt, "unit": "Hamming pairs/s",
                               "ms_per_step": round(dt / steps * 1e3, 3),
                               "collective": "all_gather of 3 x nq int per rank" if world > 1 else "none"}))
-    if world > 1:
+    if world > 1 and dist.is_initialized():
         dist.destroy_process_group()
 
 
