@@ -163,6 +163,17 @@ void orbx_matcher_destroy(orbx_matcher* m);
 int orbx_hamming_knn2_device(orbx_matcher* m, const uint8_t* d_query, int64_t nq,
                              const uint8_t* d_db, int64_t ndb, int32_t init, int64_t db_index_base,
                              int64_t* d_idx, int32_t* d_d1, int32_t* d_d2, void* stream);
+/* The same scan for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc. No counterpart in the reference. orbx_hamming_knn2_device keeps its
+ * per-chunk partial results in a buffer it grows with hipMalloc; this form keeps them in a fixed 32 MiB device
+ * array that is part of the library (one copy per GPU, held until the process ends) and calls no hipMalloc,
+ * hipFree or other allocating routine. Same arguments and results. Limit: nq * ceil(ndb / 4194304) must not
+ * exceed 2,097,152 (e.g. 65,536 queries x 134 M rows, or 2 M queries x 4 M rows); larger problems return
+ * ORBX_ERR_CAPACITY and change nothing. All calls on one GPU share that GPU's array: calls that overlap in time on
+ * one GPU (different streams or matchers) race; calls on one stream, or ordered by events, are safe. */
+int orbx_hamming_knn2_noalloc_device(orbx_matcher* m, const uint8_t* d_query, int64_t nq,
+                                     const uint8_t* d_db, int64_t ndb, int32_t init, int64_t db_index_base,
+                                     int64_t* d_idx, int32_t* d_d1, int32_t* d_d2, void* stream);
 /* Host-buffer form (H2D, scan, D2H; blocks). */
 int orbx_hamming_knn2(orbx_matcher* m, const uint8_t* query, int64_t nq, const uint8_t* db,
                       int64_t ndb, int32_t init, int64_t* idx, int32_t* d1, int32_t* d2);

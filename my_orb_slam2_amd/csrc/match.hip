@@ -15,6 +15,7 @@
 #include "orbx_internal.h"
 
 #include <cmath>
+#include <mutex>
 
 namespace orbx {
 
@@ -489,15 +490,12 @@ size_t knn2_scratch_bytes(int64_t nq, int64_t ndb) {
     return (size_t)nchunks * (size_t)nq * sizeof(Partial);
 }
 
-hipError_t launch_knn2(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb, int32_t init,
-                       int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2, void* scratch,
-                       size_t scratchBytes, hipStream_t s) {
-    if (nq <= 0) return hipSuccess;
-    const int64_t rows = pick_chunk_rows(nq, ndb);
-    const int64_t nchunks = ndb > 0 ? (ndb + rows - 1) / rows : 0;
-    if ((size_t)nchunks * (size_t)nq * sizeof(Partial) > scratchBytes) return hipErrorInvalidValue;
+namespace {
+// The scan over chunks of `rows` database rows into `part`, then the fold in chunk order.
+hipError_t launch_knn2_chunks(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb, int64_t rows,
+                              int64_t nchunks, int32_t init, int64_t indexBase, int64_t* idx, int32_t* d1,
+                              int32_t* d2, Partial* part, hipStream_t s) {
     if (nchunks > 65535) return hipErrorInvalidValue;
-    Partial* part = static_cast<Partial*>(scratch);
     const unsigned qblocks = (unsigned)((nq + kQueriesPerBlock - 1) / kQueriesPerBlock);
     if (nchunks > 0) {
         dim3 grid(qblocks, (unsigned)nchunks, 1), block(kQueriesPerBlock, 1, 1);
@@ -509,6 +507,87 @@ hipError_t launch_knn2(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t 
     hipLaunchKernelGGL(knn2_fold_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, part,
                        (int)nchunks, nq, init, idx, d1, d2);
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_knn2(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb, int32_t init,
+                       int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2, void* scratch,
+                       size_t scratchBytes, hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    const int64_t rows = pick_chunk_rows(nq, ndb);
+    const int64_t nchunks = ndb > 0 ? (ndb + rows - 1) / rows : 0;
+    if ((size_t)nchunks * (size_t)nq * sizeof(Partial) > scratchBytes) return hipErrorInvalidValue;
+    return launch_knn2_chunks(q, nq, db, ndb, rows, nchunks, init, indexBase, idx, d1, d2,
+                              static_cast<Partial*>(scratch), s);
+}
+
+// ---- the same scan for callers that cannot allocate ---------------------------------------------
+// The per-chunk partial results live in a fixed array inside the library's code object instead of a buffer
+// from hipMalloc. Every GPU the library runs on holds its own copy of the array, at its own address, until the
+// process ends. In host code the array's name is only a handle for hipGetSymbolAddress; the address a kernel
+// can use is looked up once per device and kept in g_staticPartial.
+constexpr size_t kStaticPartialBytes = (size_t)32 << 20;
+constexpr int64_t kStaticPartials = (int64_t)(kStaticPartialBytes / sizeof(Partial));   // 2 Mi (query, chunk) pairs
+constexpr int kMaxStaticDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kStaticPartialBytes];
+
+namespace {
+std::mutex g_staticMutex;
+Partial* g_staticPartial[kMaxStaticDevices] = {};
+
+// Chunking that keeps nq * nchunks partials inside the fixed array; false when no chunking does.
+bool pick_chunks_bounded(int64_t nq, int64_t ndb, int64_t* rowsOut, int64_t* nchunksOut) {
+    if (nq > kStaticPartials) return false;
+    int64_t rows = pick_chunk_rows(nq, ndb);
+    int64_t nchunks = ndb > 0 ? (ndb + rows - 1) / rows : 0;
+    if (nchunks * nq > kStaticPartials) {
+        nchunks = kStaticPartials / nq;                  // >= 1
+        rows = (ndb + nchunks - 1) / nchunks;
+        if (rows > kMaxChunkRows) return false;          // the row offset must fit its 23-bit key field
+        nchunks = (ndb + rows - 1) / rows;
+    }
+    *rowsOut = rows;
+    *nchunksOut = nchunks;
+    return true;
+}
+}  // namespace
+
+int64_t knn2_static_max_partials() { return kStaticPartials; }
+
+bool knn2_static_fits(int64_t nq, int64_t ndb) {
+    int64_t rows, nchunks;
+    return pick_chunks_bounded(nq, ndb, &rows, &nchunks);
+}
+
+// Looks up this device's copy of the array. `device` must be the current device.
+hipError_t knn2_static_init(int device) {
+    if (device < 0 || device >= kMaxStaticDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_staticMutex);
+    if (g_staticPartial[device]) return hipSuccess;
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_staticPartial[device] = static_cast<Partial*>(p);
+    return hipSuccess;
+}
+
+// `device` must be the current device and knn2_static_fits(nq, ndb) must hold. Every partial the fold reads is
+// written by the scan of the same call, so nothing in the array has to be cleared between calls.
+hipError_t launch_knn2_static(int device, const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb,
+                              int32_t init, int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2,
+                              hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    int64_t rows = 0, nchunks = 0;
+    if (!pick_chunks_bounded(nq, ndb, &rows, &nchunks)) return hipErrorInvalidValue;
+    hipError_t e = knn2_static_init(device);
+    if (e != hipSuccess) return e;
+    Partial* part;
+    {
+        std::lock_guard<std::mutex> lock(g_staticMutex);
+        part = g_staticPartial[device];
+    }
+    return launch_knn2_chunks(q, nq, db, ndb, rows, nchunks, init, indexBase, idx, d1, d2, part, s);
 }
 
 hipError_t launch_knn2_merge(int nparts, int64_t nq, const int64_t* idx, const int32_t* d1,

@@ -690,6 +690,7 @@ extern "C" int orbx_matcher_create(int device, orbx_matcher** out) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->scale), sizeof(float) * 2 * ORBX_MAX_LEVELS);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&m->evIn[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->evOut, hipEventDisableTiming);
+    if (e == hipSuccess) e = knn2_static_init(device);   // address of this device's fixed partial-result array
     if (e != hipSuccess) {
         set_error("orbx_matcher_create: %s", hipGetErrorString(e));
         orbx_matcher_destroy(m);
@@ -742,6 +743,28 @@ extern "C" int orbx_hamming_knn2_device(orbx_matcher* m, const uint8_t* d_query,
     if (rc) return rc;
     HIP_TRY(launch_knn2(d_query, nq, d_db, ndb, init, db_index_base, d_idx, d_d1, d_d2, m->scratch,
                         m->scratchBytes, s));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_hamming_knn2_noalloc_device(orbx_matcher* m, const uint8_t* d_query, int64_t nq,
+                                                const uint8_t* d_db, int64_t ndb, int32_t init,
+                                                int64_t db_index_base, int64_t* d_idx, int32_t* d_d1, int32_t* d_d2,
+                                                void* stream) {
+    if (!m || nq < 0 || ndb < 0 || ndb > INT32_MAX || (nq > 0 && (!d_query || !d_idx || !d_d1 || !d_d2)) ||
+        (ndb > 0 && !d_db) || ((uintptr_t)d_query % 16) || ((uintptr_t)d_db % 16)) {
+        set_error("orbx_hamming_knn2_noalloc_device: bad argument (descriptor arrays must be 16-byte aligned)");
+        return ORBX_ERR_INVALID;
+    }
+    if (nq == 0) return ORBX_OK;
+    if (!knn2_static_fits(nq, ndb)) {
+        set_error("orbx_hamming_knn2_noalloc_device: %lld queries x %lld rows do not fit the fixed partial-result "
+                  "array (nq * ceil(ndb / 4194304) must not exceed %lld); use orbx_hamming_knn2_device",
+                  (long long)nq, (long long)ndb, (long long)knn2_static_max_partials());
+        return ORBX_ERR_CAPACITY;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+    HIP_TRY(launch_knn2_static(m->device, d_query, nq, d_db, ndb, init, db_index_base, d_idx, d_d1, d_d2, s));
     return ORBX_OK;
 }
 

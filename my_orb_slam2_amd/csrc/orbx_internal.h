@@ -141,6 +141,13 @@ hipError_t launch_knn2(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t 
                        int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2, void* scratch,
                        size_t scratchBytes, hipStream_t s);
 size_t knn2_scratch_bytes(int64_t nq, int64_t ndb);
+// The scan with its per-chunk partial results in a fixed device array of the library (no allocation).
+int64_t knn2_static_max_partials();
+bool knn2_static_fits(int64_t nq, int64_t ndb);
+hipError_t knn2_static_init(int device);
+hipError_t launch_knn2_static(int device, const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb,
+                              int32_t init, int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2,
+                              hipStream_t s);
 hipError_t launch_knn2_merge(int nparts, int64_t nq, const int64_t* idx, const int32_t* d1,
                              const int32_t* d2, int32_t init, int64_t* oidx, int32_t* od1, int32_t* od2,
                              hipStream_t s);

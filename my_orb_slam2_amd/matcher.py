@@ -66,11 +66,13 @@ class HammingMatcher:
                                       np_ptr(idx), np_ptr(d1), np_ptr(d2)), "orbx_hamming_knn2")
         return idx, d1, d2
 
-    def knn2_device(self, d_query, d_db, d_idx, d_d1, d_d2, init=256, index_base=0, stream=None):
-        """torch CUDA tensors: (nq, 32) / (ndb, 32) uint8 in, int64 / int32 / int32 (nq,) out."""
+    def knn2_device(self, d_query, d_db, d_idx, d_d1, d_d2, init=256, index_base=0, stream=None, noalloc=False):
+        """torch CUDA tensors: (nq, 32) / (ndb, 32) uint8 in, int64 / int32 / int32 (nq,) out.
+        noalloc: the entry point that keeps its partial results in the library's fixed device array."""
         sp = C.c_void_p(stream) if stream else None
         self._before(stream)
-        check(lib().orbx_hamming_knn2_device(self._m, C.c_void_p(d_query.data_ptr()), d_query.shape[0],
+        fn = lib().orbx_hamming_knn2_noalloc_device if noalloc else lib().orbx_hamming_knn2_device
+        check(fn(self._m, C.c_void_p(d_query.data_ptr()), d_query.shape[0],
                                              C.c_void_p(d_db.data_ptr()), d_db.shape[0], int(init),
                                              int(index_base), C.c_void_p(d_idx.data_ptr()),
                                              C.c_void_p(d_d1.data_ptr()), C.c_void_p(d_d2.data_ptr()), sp),
