@@ -87,10 +87,10 @@ int orbx_get_scale_sigma_squares(const orbx_ctx* ctx, float* out);
 int orbx_get_inverse_scale_sigma_squares(const orbx_ctx* ctx, float* out);
 int orbx_get_features_per_level(const orbx_ctx* ctx, int32_t* out); /* mnFeaturesPerLevel (:427-438) */
 int orbx_get_umax(const orbx_ctx* ctx, int32_t* out16);              /* umax (:446-461) */
-/* Capacity for images of the context's maximum size: sum over levels of max(quota + 3, 4 * nIni). A level
+/* A capacity no image the context accepts can exceed: sum over levels of max(quota + 3, 4 * nIniMax). A level
  * yields at most quota + 3 keypoints once the node list nears the quota (src/ORBextractor.cc:661-723), but the
- * first sweep splits all nIni = round(width / height) root nodes whatever the quota (:598-657). A smaller
- * image with a more extreme aspect ratio can need more; the extract calls report ORBX_ERR_CAPACITY then. */
+ * first sweep splits all nIni = round(width / height) root nodes whatever the quota (:598-657); nIniMax is the
+ * nIni of the flattest strip of max_width that still has a row of FAST cells. */
 int orbx_keypoint_capacity(const orbx_ctx* ctx);
 
 /* ORBextractor::operator() (src/ORBextractor.cc:1035-1097) on one host image (CV_8UC1 rows of
@@ -107,7 +107,12 @@ int orbx_extract(orbx_ctx* ctx, const uint8_t* image, int width, int height, siz
  * stored). Work is enqueued on `stream` (a hipStream_t; NULL = the context's own stream) and the
  * call returns without waiting. Frames are read in place when d_images, row_stride and frame_stride are
  * multiples of 4; otherwise the call first copies them into an aligned buffer of its own (one extra pass
- * over the pixels), so tightly packed odd widths and views into larger images work, a little slower. */
+ * over the pixels), so tightly packed odd widths and views into larger images work, a little slower.
+ * Frames read in place are read in whole dwords up to row_stride in every row: height * row_stride bytes per
+ * frame must be readable, also in the last row of the last frame (a view into a larger allocation satisfies
+ * this by itself; the host entry points copy exactly `width` bytes per row and have no such requirement).
+ * A context may be driven from different streams in turn: a call on another stream than the previous one first
+ * waits (on the device) for the previous call, since all calls share the context's buffers. */
 int orbx_extract_batch_device(orbx_ctx* ctx, const uint8_t* d_images, int nframes, int width,
                               int height, size_t row_stride, size_t frame_stride,
                               orbx_keypoint* d_keypoints, uint8_t* d_descriptors, int cap,

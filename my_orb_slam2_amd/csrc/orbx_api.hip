@@ -50,6 +50,9 @@ struct orbx_ctx {
     bool profiling = false;
     bool haveTimes = false;
     hipEvent_t ev[ORBX_NUM_STAGES + 1] = {};
+    // recorded behind every batched call: a later call on another stream waits for it before it reuses the
+    // context's buffers
+    hipEvent_t evDone = nullptr;
 };
 
 namespace {
@@ -71,6 +74,7 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
         return ORBX_ERR_INVALID;
     }
     if (g.totalCells > c->maxGeom.totalCells || g.totalSlots > c->maxGeom.totalSlots ||
+        g.totalSel > c->maxGeom.totalSel || octree_lds_bytes(g) > 160 * 1024 ||
         g.pyrBytes > c->maxGeom.pyrBytes || w > c->cfg.max_width || h > c->cfg.max_height) {
         set_error("image %dx%d exceeds the context's maximum %dx%d", w, h, c->cfg.max_width,
                   c->cfg.max_height);
@@ -129,6 +133,8 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
     return ORBX_OK;
 }
 
+int max_root_nodes(const orbx_config& cfg);
+
 int check_ctx(const orbx_ctx* c) {
     if (!c) {
         set_error("null context");
@@ -178,6 +184,16 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_ctx** out) {
     mg.totalCells = mg.totalCells + mg.totalCells / 4 + 64;
     mg.totalSlots = mg.totalSlots + mg.totalSlots / 2 + 4096;
     mg.pyrBytes += 4096;
+    // The selected-keypoint region of a level holds max(quota + 4, 4 * nIni + 1) entries and nIni =
+    // round(width / height) of the level grows with the aspect ratio, not with the size: a flat strip of the
+    // largest width has the most roots any admissible image can have (a level needs 30 rows inside its border to
+    // have cells at all).
+    {
+        const int nIniMax = max_root_nodes(*cfg);
+        int sel = 0;
+        for (int l = 0; l < mg.nlevels; l++) sel += std::max(c->tab.perLevel[l] + kSelPad, 4 * nIniMax + 1);
+        mg.totalSel = std::max(mg.totalSel, sel);
+    }
     const size_t B = (size_t)cfg->max_batch;
     int rc = ORBX_OK;
     auto fail = [&](int code) {
@@ -187,6 +203,11 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_ctx** out) {
     hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (he != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(he));
+        return fail(ORBX_ERR_HIP);
+    }
+    he = hipEventCreateWithFlags(&c->evDone, hipEventDisableTiming);
+    if (he != hipSuccess) {
+        set_error("hipEventCreate failed: %s", hipGetErrorString(he));
         return fail(ORBX_ERR_HIP);
     }
     if ((rc = dev_alloc(&c->fs.pyr, B * (size_t)mg.pyrBytes))) return fail(rc);
@@ -212,6 +233,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (c->pinIn) (void)hipHostFree(c->pinIn);
     for (hipEvent_t e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    if (c->evDone) (void)hipEventDestroy(c->evDone);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -238,11 +260,20 @@ extern "C" int orbx_get_umax(const orbx_ctx* c, int32_t* out16) {
     std::copy(c->tab.umax, c->tab.umax + kHalfPatch + 1, out16);
     return ORBX_OK;
 }
+namespace {
+// Most quadtree roots any image a context accepts can have: nIni = round(width / height) of a level inside its
+// border (src/ORBextractor.cc:535), largest for a strip of the full width and the 30 rows a level needs for one cell.
+int max_root_nodes(const orbx_config& cfg) {
+    return (int)std::lround((double)std::max(cfg.max_width - 2 * kBorder, 0) / kCellSize) + 1;
+}
+}  // namespace
+
 extern "C" int orbx_keypoint_capacity(const orbx_ctx* c) {
     if (!c) return 0;
-    // per level max(quota + 3, 4 * nIni), nIni taken from the context's largest image
+    // per level max(quota + 3, 4 * nIni), with the largest nIni any admissible image has
+    const int nIniMax = max_root_nodes(c->cfg);
     int cap = 0;
-    for (int l = 0; l < c->maxGeom.nlevels; l++) cap += std::max(c->tab.perLevel[l] + 3, 4 * c->maxGeom.lv[l].nIni);
+    for (int l = 0; l < c->maxGeom.nlevels; l++) cap += std::max(c->tab.perLevel[l] + 3, 4 * nIniMax);
     return cap;
 }
 
@@ -281,6 +312,9 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, i
     HIP_TRY(hipSetDevice(c->cfg.device));
     if ((rc = ensure_geometry(c, width, height))) return rc;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    // The context's buffers (pyramid, candidates, selection, staging) are shared by all its calls: work queued on
+    // another stream than the previous call's starts only after that call has finished with them.
+    if (c->lastStream && c->lastStream != s) HIP_TRY(hipStreamWaitEvent(s, c->evDone, 0));
     FrameSet fs = c->fs;
     if (nframes == 1) frame_stride = 0;                 // never used to address anything
     if ((uintptr_t)d_images % 4 || row_stride % 4 || frame_stride % 4) {
@@ -311,6 +345,7 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, i
     if (prof) HIP_TRY(hipEventRecord(c->ev[3], s));
     HIP_TRY(launch_orient_desc(fs, g, nframes, c->cfg.blur_taps, d_kps, d_desc, cap, d_counts, s));
     if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
+    HIP_TRY(hipEventRecord(c->evDone, s));
     c->haveTimes = prof;
     return ORBX_OK;
 }

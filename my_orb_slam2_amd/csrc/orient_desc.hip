@@ -166,8 +166,10 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-// sin and cos of x in [0, 8] to within an ulp of double (the reference takes cos/sin of the angle in double and
-// rounds to float, src/ORBextractor.cc:103-104). Quadrant reduction with a two-part pi/2, then the
+// sin and cos of x in [0, 8] to within an ulp of double; rounded to float afterwards this is the correctly rounded
+// float value in all but vanishingly rare cases. The reference calls the float overloads of cos / sin
+// (src/ORBextractor.cc:103-104 under `using namespace std`), i.e. cosf / sinf of its C runtime, whose last bit
+// differs between runtimes; the correctly rounded value is the runtime-independent choice. Quadrant reduction with a two-part pi/2, then the
 // minimax polynomials of fdlibm's __kernel_sin / __kernel_cos on |r| <= pi/4.
 // a * b + k with the constant k held in scalar registers (v_fma_f64 takes one SGPR source; left to itself the
 // compiler picks v_fmac_f64 and spends two v_mov per coefficient to seed the accumulator)

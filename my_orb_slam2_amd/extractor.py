@@ -84,7 +84,7 @@ class ORBextractor:
 
     @property
     def capacity(self):
-        """Keypoint capacity that can never overflow (sum of per-level quota + 3)."""
+        """Keypoint capacity that no image the context accepts can overflow (orbx_keypoint_capacity)."""
         return self._capacity
 
     # ---- operator() (src/ORBextractor.cc:1035-1097) ----
@@ -118,6 +118,8 @@ class ORBextractor:
         check(lib().orbx_extract_batch(self._ctx, np_ptr(images), b, w, h, images.strides[1], images.strides[0],
                                        np_ptr(kps), np_ptr(desc), cap, np_ptr(counts)), "orbx_extract_batch")
         self._last_shape = (b, h, w)
+        if int(counts.max(initial=0)) > cap:
+            raise RuntimeError("orbx_extract_batch: %d keypoints in a frame, capacity %d" % (int(counts.max()), cap))
         return [(kps[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(b)]
 
     def extract_batch_device(self, d_images, d_keypoints, d_descriptors, d_counts, stream=None):

@@ -140,22 +140,43 @@ inline void WriteKeyPoints(std::ostream& f, const std::vector<orbx_keypoint>& kp
     f.write(reinterpret_cast<const char*>(&size), sizeof(size));
     f.write(reinterpret_cast<const char*>(kps.data()), static_cast<std::streamsize>(size * sizeof(orbx_keypoint)));
 }
-inline void ReadKeyPoints(std::istream& f, std::vector<orbx_keypoint>& kps) {
+// Bytes left between the read position and the end of a seekable stream; "unknown" (max) for others.
+inline uint64_t StreamBytesLeft(std::istream& f) {
+    const std::istream::pos_type here = f.tellg();
+    if (here == std::istream::pos_type(-1)) return UINT64_MAX;
+    f.seekg(0, std::ios::end);
+    const std::istream::pos_type end = f.tellg();
+    f.seekg(here);
+    return end >= here ? static_cast<uint64_t>(end - here) : 0;
+}
+// Returns false (and leaves kps empty) on a short read or a count the rest of the file cannot hold.
+inline bool ReadKeyPoints(std::istream& f, std::vector<orbx_keypoint>& kps) {
+    kps.clear();
     uint64_t size = 0;
     f.read(reinterpret_cast<char*>(&size), sizeof(size));
+    if (!f.good() || size > StreamBytesLeft(f) / sizeof(orbx_keypoint)) return false;
     kps.resize(size);
     f.read(reinterpret_cast<char*>(kps.data()), static_cast<std::streamsize>(size * sizeof(orbx_keypoint)));
+    if (!f.good()) kps.clear();
+    return f.good();
 }
 inline void WriteDescriptors(std::ostream& f, const std::vector<uint8_t>& desc) {
     const uint32_t header[3] = {static_cast<uint32_t>(desc.size() / ORBX_DESC_BYTES), ORBX_DESC_BYTES, 0u};
     f.write(reinterpret_cast<const char*>(header), sizeof(header));
     f.write(reinterpret_cast<const char*>(desc.data()), static_cast<std::streamsize>(desc.size()));
 }
-inline void ReadDescriptors(std::istream& f, std::vector<uint8_t>& desc) {
+// Returns false (and leaves desc empty) on a short read or a header that is not rows x 32 of CV_8UC1.
+inline bool ReadDescriptors(std::istream& f, std::vector<uint8_t>& desc) {
+    desc.clear();
     uint32_t header[3] = {0, 0, 0};
     f.read(reinterpret_cast<char*>(header), sizeof(header));
-    desc.resize(static_cast<size_t>(header[0]) * header[1]);
+    if (!f.good() || header[1] != ORBX_DESC_BYTES || header[2] != 0u ||
+        header[0] > StreamBytesLeft(f) / ORBX_DESC_BYTES)
+        return false;
+    desc.resize(static_cast<size_t>(header[0]) * ORBX_DESC_BYTES);
     f.read(reinterpret_cast<char*>(desc.data()), static_cast<std::streamsize>(desc.size()));
+    if (!f.good()) desc.clear();
+    return f.good();
 }
 
 }  // namespace ORB_SLAM2

@@ -491,6 +491,7 @@ extern "C" orc_extractor* orc_create(int nfeatures, float scaleFactor, int nleve
 }
 
 extern "C" void orc_destroy(orc_extractor* e) { delete e; }
+
 extern "C" int orc_levels(const orc_extractor* e) { return e->nlevels; }
 extern "C" void orc_scale_factors(const orc_extractor* e, float* s, float* is, float* g, float* ig) {
     for (int i = 0; i < e->nlevels; i++) {
@@ -563,12 +564,19 @@ float ic_angle(const uint8_t* center, long step, const std::vector<int>& umax) {
     return orc_fast_atan2((float)m_01, (float)m_10);
 }
 
-/* computeOrbDescriptor (src/ORBextractor.cc:99-139).  cos/sin: (float) of the double-precision
- * value; products and the sum are separate float roundings (no FMA). */
+/* computeOrbDescriptor (src/ORBextractor.cc:99-139).  The reference writes cos(angle) / sin(angle) on a float
+ * under `using namespace std` (include/ORBextractor.h:28), i.e. the float overloads = cosf / sinf of whatever C
+ * runtime it is built with (MSVC's there). Their last bit is not specified: glibc's cosf / sinf differ from the
+ * correctly rounded value for 0.04 % / 0.09 % of the floats in [0, 2 pi] and pick FMA or non-FMA variants by CPU.
+ * g_trig_mode 0 (default) takes the correctly rounded value, which no runtime can improve on: (float) of the
+ * double-precision result; mode 1 calls this runtime's cosf / sinf, to measure how much the choice matters.
+ * Products and the sum are separate float roundings (no FMA). */
+int g_trig_mode = 0;
 void orb_descriptor(const orc_keypoint& kp, const uint8_t* img, long step, uint8_t* desc) {
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float angle = kp.angle * factorPI;
-    const float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
+    const float a = g_trig_mode ? cosf(angle) : (float)std::cos((double)angle);
+    const float b = g_trig_mode ? sinf(angle) : (float)std::sin((double)angle);
     const uint8_t* center = img + (long)cv_round(kp.y) * step + cv_round(kp.x);
     const int* pat = kPattern;
     for (int i = 0; i < 32; ++i, pat += 32) {
@@ -672,6 +680,8 @@ int extract_impl(orc_extractor* e, const uint8_t* img, int w, int h, long stride
 }
 
 }  // namespace
+
+extern "C" void orc_set_trig_mode(int libm_float) { g_trig_mode = libm_float != 0; }
 
 extern "C" int orc_extract(orc_extractor* e, const uint8_t* img, int w, int h, long stride,
                            orc_keypoint* kps, uint8_t* desc, int cap) {

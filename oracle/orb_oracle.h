@@ -53,6 +53,10 @@ typedef struct orc_extractor orc_extractor;
 orc_extractor* orc_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
                           int minThFAST, int blur_variant);
 void  orc_destroy(orc_extractor* e);
+/* How computeOrbDescriptor (src/ORBextractor.cc:103-104) takes cos / sin of the keypoint angle, for every
+ * extractor of the process: 0 (default) = the correctly rounded float value, 1 = this C runtime's cosf / sinf
+ * (what the reference's call resolves to, with the last-bit behaviour of whatever runtime it is built against). */
+void  orc_set_trig_mode(int libm_float);
 /* ORBextractor::operator() (:1035-1097). Returns the number of keypoints (<= cap stored),
  * or -1 on bad arguments. An empty image returns 0 and leaves outputs untouched. */
 int   orc_extract(orc_extractor* e, const uint8_t* img, int w, int h, long stride,

@@ -1,7 +1,9 @@
 // Exercises the C++ shim the way Frame::ExtractORB does and prints a digest that the Python test
 // compares with the oracle's result for the same synthetic frame.
 #include <cstdio>
+#include <cstring>
 #include <sstream>
+#include <string>
 #include <vector>
 
 #include "ORBextractorGpu.h"
@@ -27,9 +29,27 @@ int main() {
     if (ss.str().size() != 8 + 28 * k.size() + 12 + d.size()) return 4;
     std::vector<orbx_keypoint> kb;
     std::vector<uint8_t> db;
-    ORB_SLAM2::ReadKeyPoints(ss, kb);
-    ORB_SLAM2::ReadDescriptors(ss, db);
+    if (!ORB_SLAM2::ReadKeyPoints(ss, kb) || !ORB_SLAM2::ReadDescriptors(ss, db)) return 5;
     if (kb.size() != k.size() || std::memcmp(kb.data(), k.data(), 28 * k.size()) != 0 || db != d) return 5;
+    {
+        // corrupt blocks are refused without a huge allocation: a count the file cannot hold, a truncated
+        // block, a descriptor header that is not rows x 32 of CV_8UC1
+        const std::string good = ss.str();
+        std::string bad = good;
+        bad[6] = 0x7f;                                            // count = 2^55 or so
+        std::stringstream s1(bad);
+        if (ORB_SLAM2::ReadKeyPoints(s1, kb) || !kb.empty()) return 6;
+        std::stringstream s2(good.substr(0, 8 + 28 * k.size() - 5));
+        if (ORB_SLAM2::ReadKeyPoints(s2, kb) || !kb.empty()) return 6;
+        for (int field = 1; field <= 2; field++) {
+            bad = good;
+            bad[8 + 28 * k.size() + 4 * field] ^= 1;              // cols 33, then type 1
+            std::stringstream s3(bad);
+            if (!ORB_SLAM2::ReadKeyPoints(s3, kb) || ORB_SLAM2::ReadDescriptors(s3, db) || !db.empty()) return 6;
+        }
+        std::stringstream s4(good.substr(0, good.size() - 1));
+        if (!ORB_SLAM2::ReadKeyPoints(s4, kb) || ORB_SLAM2::ReadDescriptors(s4, db)) return 6;
+    }
     // empty image: outputs untouched
     std::vector<orbx_keypoint> k2(3);
     std::vector<uint8_t> d2(5);

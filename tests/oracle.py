@@ -36,6 +36,8 @@ def lib():
         L.orc_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_destroy.restype = None
         L.orc_destroy.argtypes = [_P]
+        L.orc_set_trig_mode.restype = None
+        L.orc_set_trig_mode.argtypes = [C.c_int]
         for name in ("orc_extract", "orc_extract_fast"):
             fn = getattr(L, name)
             fn.restype = C.c_int
@@ -95,6 +97,11 @@ def lib():
 
 def ptr(a):
     return a.ctypes.data_as(_P)
+
+
+def set_trig_mode(libm_float):
+    """False (default): descriptor steering uses the correctly rounded cos / sin; True: this runtime's cosf / sinf."""
+    lib().orc_set_trig_mode(1 if libm_float else 0)
 
 
 def resize(src, dw, dh):

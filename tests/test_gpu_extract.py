@@ -76,6 +76,30 @@ def test_degenerate_frames():
     assert compare_frame(gpu, cpu, m.synth_frame(2, kind=synth.NOISE)) > 900
 
 
+def test_descriptor_bits_against_libm_float_trig():
+    """The reference steers the pattern with cosf / sinf of its C runtime (src/ORBextractor.cc:103-104); kernel and
+    oracle use the correctly rounded values. With the oracle switched to this runtime's cosf / sinf, a/b differ by
+    an ulp for a fraction of a percent of the angles, which matters only where it flips a cvRound tie: the per-bit
+    mismatch rate is reported and must stay below 1e-4; everything but the descriptors must not move."""
+    gpu, cpu = make()
+    bits = total = 0
+    try:
+        for i in range(8):
+            img = m.synth_frame(100 + i)
+            orc.set_trig_mode(True)
+            ck, cd = cpu.extract(img)
+            orc.set_trig_mode(False)
+            gk, gd = gpu(img)
+            assert np.array_equal(gk["x"], ck["x"]) and np.array_equal(gk["angle"] != ck["angle"], np.zeros(len(ck), bool))
+            bits += int(np.unpackbits(gd ^ cd).sum())
+            total += cd.size * 8
+    finally:
+        orc.set_trig_mode(False)
+    rate = bits / float(total)
+    print("descriptor per-bit mismatch rate against libm cosf/sinf steering: %d / %d = %.3g" % (bits, total, rate))
+    assert rate < 1e-4
+
+
 def test_blur_variant_4_2():
     gpu, cpu = make(blur=m.BLUR_CV_4_2_PLUS)
     compare_frame(gpu, cpu, m.synth_frame(7))
@@ -134,6 +158,29 @@ def test_levels_with_quota_zero_or_one():
     assert list(cpu.features_per_level()) == [2, 1, 1, 1, 0, 0]
     n = compare_frame(gpu, cpu, m.synth_frame(1038, 823, 610, kind=S.NOISE))
     assert n == 24
+
+
+@pytest.mark.parametrize("w,h", [(752, 100), (752, 70), (700, 62), (400, 300)])
+def test_strip_frames_in_a_bigger_context_with_small_quotas(w, h):
+    """A flat strip has more quadtree roots (nIni = round(width / height), src/ORBextractor.cc:535) than the
+    context's largest image and keeps up to 4 * nIni keypoints per level whatever the quota: the per-frame
+    selection buffers must be sized for that, in every frame of a batch."""
+    B = 8
+    gpu, cpu = make(nfeatures=100, w=752, h=480, batch=B)
+    frames = np.stack([m.synth_frame(40 + i, w, h, kind=synth.NOISE if i % 2 else synth.SCENE) for i in range(B)])
+    res = gpu.extract_batch(frames)
+    most = 0
+    for i in range(B):
+        ck, cd = cpu.extract(frames[i])
+        assert len(res[i][0]) == len(ck)
+        for f in ("x", "y", "size", "response", "octave"):
+            assert np.array_equal(res[i][0][f], ck[f]), (i, f)
+        assert np.array_equal(res[i][1], cd)
+        most = max(most, len(ck))
+    assert most <= gpu.capacity
+    if h == 100:
+        assert most > 100 + 3 * 8          # more than quota + 3 per level: the 4 * nIni rule was in force
+    compare_frame(gpu, cpu, frames[B - 1])
 
 
 def test_unaligned_rows_and_smaller_image_in_big_context():
