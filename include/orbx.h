@@ -188,6 +188,21 @@ int orbx_hamming_knn2(orbx_matcher* m, const uint8_t* query, int64_t nq, const u
 int orbx_knn2_merge_device(orbx_matcher* m, int nparts, int64_t nq, const int64_t* d_idx,
                            const int32_t* d_d1, const int32_t* d_d2, int32_t init,
                            int64_t* d_out_idx, int32_t* d_out_d1, int32_t* d_out_d2, void* stream);
+/* The same scan and merge with one 16-byte record per query, for a database sharded over several GPUs: every
+ * rank scans its shard into nq records, ONE all-gather of nq * 16 bytes per rank (ncclAllGather over the rank
+ * order = shard order) leaves part p of query i at d_hits[p * nq + i], and the merge folds them exactly as a
+ * single scan over the whole database would have (src/ORBmatcher.cc:204-229: lowest row wins ties, second best
+ * = second smallest of all d1 and d2). A record with idx = -1 carries d1 = d2 = init. */
+typedef struct orbx_knn2_hit {
+    int32_t d1, d2;
+    int64_t idx;
+} orbx_knn2_hit;
+int orbx_hamming_knn2_packed_device(orbx_matcher* m, const uint8_t* d_query, int64_t nq, const uint8_t* d_db,
+                                    int64_t ndb, int32_t init, int64_t db_index_base, orbx_knn2_hit* d_hits,
+                                    void* stream);
+int orbx_knn2_merge_packed_device(orbx_matcher* m, int nparts, int64_t nq, const orbx_knn2_hit* d_hits,
+                                  int32_t init, int64_t* d_out_idx, int32_t* d_out_d1, int32_t* d_out_d2,
+                                  void* stream);
 /* Acceptance test of the callers: d1 <= th (inclusive != 0: src/ORBmatcher.cc:231,467) or d1 < th
  * (:619), then (float)d1 < ratio*(float)d2 (:233,469,621). accept receives nq bytes (0/1). */
 int orbx_ratio_test_device(orbx_matcher* m, int64_t nq, const int32_t* d_d1, const int32_t* d_d2,

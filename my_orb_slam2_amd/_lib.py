@@ -75,6 +75,8 @@ SIGNATURES = {
                                                    _P, _P, _P, _P]),
     "orbx_hamming_knn2": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     "orbx_knn2_merge_device": (C.c_int, [_P, C.c_int, C.c_int64, _P, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    "orbx_hamming_knn2_packed_device": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int64, _P, _P]),
+    "orbx_knn2_merge_packed_device": (C.c_int, [_P, C.c_int, C.c_int64, _P, C.c_int32, _P, _P, _P, _P]),
     "orbx_ratio_test_device": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int32, C.c_int, C.c_float, _P, _P]),
     "orbx_stereo_band_match_device": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P,
                                                 C.c_int, C.c_float, C.c_float, _P, _P, _P]),

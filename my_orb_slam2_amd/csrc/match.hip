@@ -15,6 +15,7 @@
 #include "orbx_internal.h"
 
 #include <cmath>
+#include <cstddef>
 #include <mutex>
 
 namespace orbx {
@@ -102,9 +103,11 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn2_kernel(const uint4* __r
 
 // Folds the per-chunk partials of one query in chunk (= index) order with the reference's update
 // rule, then applies the start value `init`: a distance that is not < init never replaces it.
+// Results go to three arrays, or (hits != nullptr) to one array of packed 16-byte records.
 __global__ __launch_bounds__(256) void knn2_fold_kernel(const Partial* __restrict__ partial, int nchunks,
                                                         int64_t nq, int32_t init, int64_t* __restrict__ idx,
-                                                        int32_t* __restrict__ d1, int32_t* __restrict__ d2) {
+                                                        int32_t* __restrict__ d1, int32_t* __restrict__ d2,
+                                                        Partial* __restrict__ hits) {
     const int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (qi >= nq) return;
     int32_t b1 = init, b2 = init;
@@ -114,6 +117,14 @@ __global__ __launch_bounds__(256) void knn2_fold_kernel(const Partial* __restric
         if (p.d1 < b1) { b2 = b1; b1 = p.d1; bi = p.idx; }
         else if (p.d1 < b2) b2 = p.d1;
         if (p.d2 < b2) b2 = p.d2;
+    }
+    if (hits) {
+        Partial h;
+        h.d1 = b1;
+        h.d2 = b2;
+        h.idx = bi;
+        hits[qi] = h;
+        return;
     }
     idx[qi] = bi;
     d1[qi] = b1;
@@ -136,6 +147,27 @@ __global__ __launch_bounds__(256) void knn2_merge_kernel(int nparts, int64_t nq,
         if (ai >= 0 && a1 < b1) { b2 = b1; b1 = a1; bi = ai; }
         else if (ai >= 0 && a1 < b2) b2 = a1;
         if (a2 < b2) b2 = a2;
+    }
+    oidx[qi] = bi;
+    od1[qi] = b1;
+    od2[qi] = b2;
+}
+
+// The same fold over packed records: part p of query qi sits at hits[p * nq + qi], the layout one all-gather of every
+// rank's nq records produces.
+__global__ __launch_bounds__(256) void knn2_merge_packed_kernel(int nparts, int64_t nq,
+                                                                const Partial* __restrict__ hits, int32_t init,
+                                                                int64_t* __restrict__ oidx, int32_t* __restrict__ od1,
+                                                                int32_t* __restrict__ od2) {
+    const int64_t qi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    int32_t b1 = init, b2 = init;
+    int64_t bi = -1;
+    for (int p = 0; p < nparts; p++) {
+        const Partial h = hits[(int64_t)p * nq + qi];
+        if (h.idx >= 0 && h.d1 < b1) { b2 = b1; b1 = h.d1; bi = h.idx; }
+        else if (h.idx >= 0 && h.d1 < b2) b2 = h.d1;
+        if (h.d2 < b2) b2 = h.d2;
     }
     oidx[qi] = bi;
     od1[qi] = b1;
@@ -494,7 +526,7 @@ namespace {
 // The scan over chunks of `rows` database rows into `part`, then the fold in chunk order.
 hipError_t launch_knn2_chunks(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb, int64_t rows,
                               int64_t nchunks, int32_t init, int64_t indexBase, int64_t* idx, int32_t* d1,
-                              int32_t* d2, Partial* part, hipStream_t s) {
+                              int32_t* d2, void* hits, Partial* part, hipStream_t s) {
     if (nchunks > 65535) return hipErrorInvalidValue;
     const unsigned qblocks = (unsigned)((nq + kQueriesPerBlock - 1) / kQueriesPerBlock);
     if (nchunks > 0) {
@@ -505,19 +537,23 @@ hipError_t launch_knn2_chunks(const uint8_t* q, int64_t nq, const uint8_t* db, i
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(knn2_fold_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, part,
-                       (int)nchunks, nq, init, idx, d1, d2);
+                       (int)nchunks, nq, init, idx, d1, d2, static_cast<Partial*>(hits));
     return hipGetLastError();
 }
 }  // namespace
 
+static_assert(sizeof(Partial) == sizeof(orbx_knn2_hit) && offsetof(Partial, idx) == offsetof(orbx_knn2_hit, idx) &&
+                  offsetof(Partial, d2) == offsetof(orbx_knn2_hit, d2),
+              "the per-chunk partial result and the packed result record share one layout");
+
 hipError_t launch_knn2(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb, int32_t init,
-                       int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2, void* scratch,
+                       int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2, void* hits, void* scratch,
                        size_t scratchBytes, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
     const int64_t rows = pick_chunk_rows(nq, ndb);
     const int64_t nchunks = ndb > 0 ? (ndb + rows - 1) / rows : 0;
     if ((size_t)nchunks * (size_t)nq * sizeof(Partial) > scratchBytes) return hipErrorInvalidValue;
-    return launch_knn2_chunks(q, nq, db, ndb, rows, nchunks, init, indexBase, idx, d1, d2,
+    return launch_knn2_chunks(q, nq, db, ndb, rows, nchunks, init, indexBase, idx, d1, d2, hits,
                               static_cast<Partial*>(scratch), s);
 }
 
@@ -587,7 +623,7 @@ hipError_t launch_knn2_static(int device, const uint8_t* q, int64_t nq, const ui
         std::lock_guard<std::mutex> lock(g_staticMutex);
         part = g_staticPartial[device];
     }
-    return launch_knn2_chunks(q, nq, db, ndb, rows, nchunks, init, indexBase, idx, d1, d2, part, s);
+    return launch_knn2_chunks(q, nq, db, ndb, rows, nchunks, init, indexBase, idx, d1, d2, nullptr, part, s);
 }
 
 hipError_t launch_knn2_merge(int nparts, int64_t nq, const int64_t* idx, const int32_t* d1,
@@ -596,6 +632,14 @@ hipError_t launch_knn2_merge(int nparts, int64_t nq, const int64_t* idx, const i
     if (nq <= 0) return hipSuccess;
     hipLaunchKernelGGL(knn2_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, nparts, nq,
                        idx, d1, d2, init, oidx, od1, od2);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn2_merge_packed(int nparts, int64_t nq, const void* hits, int32_t init, int64_t* oidx,
+                                    int32_t* od1, int32_t* od2, hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(knn2_merge_packed_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, nparts, nq,
+                       static_cast<const Partial*>(hits), init, oidx, od1, od2);
     return hipGetLastError();
 }
 

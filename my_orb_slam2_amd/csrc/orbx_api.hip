@@ -776,8 +776,40 @@ extern "C" int orbx_hamming_knn2_device(orbx_matcher* m, const uint8_t* d_query,
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
     int rc = matcher_scratch(m, knn2_scratch_bytes(nq, ndb), s);
     if (rc) return rc;
-    HIP_TRY(launch_knn2(d_query, nq, d_db, ndb, init, db_index_base, d_idx, d_d1, d_d2, m->scratch,
+    HIP_TRY(launch_knn2(d_query, nq, d_db, ndb, init, db_index_base, d_idx, d_d1, d_d2, nullptr, m->scratch,
                         m->scratchBytes, s));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_hamming_knn2_packed_device(orbx_matcher* m, const uint8_t* d_query, int64_t nq,
+                                               const uint8_t* d_db, int64_t ndb, int32_t init, int64_t db_index_base,
+                                               orbx_knn2_hit* d_hits, void* stream) {
+    if (!m || nq < 0 || ndb < 0 || ndb > INT32_MAX || (nq > 0 && (!d_query || !d_hits)) || (ndb > 0 && !d_db) ||
+        ((uintptr_t)d_query % 16) || ((uintptr_t)d_db % 16) || ((uintptr_t)d_hits % 16)) {
+        set_error("orbx_hamming_knn2_packed_device: bad argument (descriptor and result arrays must be 16-byte aligned)");
+        return ORBX_ERR_INVALID;
+    }
+    if (nq == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+    int rc = matcher_scratch(m, knn2_scratch_bytes(nq, ndb), s);
+    if (rc) return rc;
+    HIP_TRY(launch_knn2(d_query, nq, d_db, ndb, init, db_index_base, nullptr, nullptr, nullptr, d_hits, m->scratch,
+                        m->scratchBytes, s));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_knn2_merge_packed_device(orbx_matcher* m, int nparts, int64_t nq, const orbx_knn2_hit* d_hits,
+                                             int32_t init, int64_t* d_out_idx, int32_t* d_out_d1, int32_t* d_out_d2,
+                                             void* stream) {
+    if (!m || nparts < 1 || nq < 0 || (nq > 0 && (!d_hits || !d_out_idx || !d_out_d1 || !d_out_d2)) ||
+        ((uintptr_t)d_hits % 16)) {
+        set_error("orbx_knn2_merge_packed_device: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+    HIP_TRY(launch_knn2_merge_packed(nparts, nq, d_hits, init, d_out_idx, d_out_d1, d_out_d2, s));
     return ORBX_OK;
 }
 

@@ -137,9 +137,12 @@ hipError_t launch_blur_level(const uint8_t* src, int w, int h, long long stride,
                              long long dstStride, int blurTaps, hipStream_t s);
 size_t octree_lds_bytes(const PyramidGeom& g);
 
+// Results go to idx / d1 / d2, or, when hits != nullptr, to nq packed orbx_knn2_hit records.
 hipError_t launch_knn2(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb, int32_t init,
-                       int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2, void* scratch,
+                       int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2, void* hits, void* scratch,
                        size_t scratchBytes, hipStream_t s);
+hipError_t launch_knn2_merge_packed(int nparts, int64_t nq, const void* hits, int32_t init, int64_t* oidx,
+                                    int32_t* od1, int32_t* od2, hipStream_t s);
 size_t knn2_scratch_bytes(int64_t nq, int64_t ndb);
 // The scan with its per-chunk partial results in a fixed device array of the library (no allocation).
 int64_t knn2_static_max_partials();

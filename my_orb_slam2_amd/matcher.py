@@ -79,6 +79,35 @@ class HammingMatcher:
               "orbx_hamming_knn2_device")
         self._hold(stream, d_query, d_db, d_idx, d_d1, d_d2)
 
+    def knn2_packed_device(self, d_query, d_db, d_hits, init=256, index_base=0, stream=None):
+        """The scan with one packed 16-byte record {int32 d1, d2; int64 idx} per query: d_hits is an (nq, 2) int64
+        (or (nq, 16) uint8) CUDA tensor, the unit one all-gather moves when the database is sharded over GPUs."""
+        assert d_hits.is_contiguous() and d_hits.numel() * d_hits.element_size() == 16 * d_query.shape[0]
+        sp = C.c_void_p(stream) if stream else None
+        self._before(stream)
+        check(lib().orbx_hamming_knn2_packed_device(self._m, C.c_void_p(d_query.data_ptr()), d_query.shape[0],
+                                                    C.c_void_p(d_db.data_ptr()), d_db.shape[0], int(init),
+                                                    int(index_base), C.c_void_p(d_hits.data_ptr()), sp),
+              "orbx_hamming_knn2_packed_device")
+        self._hold(stream, d_query, d_db, d_hits)
+
+    def merge_packed_device(self, d_hits, nparts, o_idx, o_d1, o_d2, init=256, stream=None):
+        """Fold the gathered records of `nparts` consecutive database shards (part p of query i at record
+        p * nq + i) into the result of one scan over the whole database."""
+        nq = o_idx.shape[0]
+        assert d_hits.is_contiguous() and d_hits.numel() * d_hits.element_size() == 16 * nq * nparts
+        sp = C.c_void_p(stream) if stream else None
+        self._before(stream)
+        check(lib().orbx_knn2_merge_packed_device(self._m, int(nparts), nq, C.c_void_p(d_hits.data_ptr()), int(init),
+                                                  C.c_void_p(o_idx.data_ptr()), C.c_void_p(o_d1.data_ptr()),
+                                                  C.c_void_p(o_d2.data_ptr()), sp), "orbx_knn2_merge_packed_device")
+        self._hold(stream, d_hits, o_idx, o_d1, o_d2)
+
+    def after(self):
+        """Makes torch's current stream wait (on the device) for everything queued on the matcher's stream so far."""
+        import torch
+        torch.cuda.current_stream().wait_event(self._own_stream().record_event())
+
     def merge_device(self, d_idx, d_d1, d_d2, o_idx, o_d1, o_d2, init=256, stream=None):
         """Merge (nparts, nq) partial results of consecutive database shards."""
         nparts, nq = d_idx.shape

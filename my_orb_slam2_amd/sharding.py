@@ -2,11 +2,13 @@
 
 Extraction and stereo matching need no communication (frame / pair k belongs to rank k mod G).
 The brute-force kNN over a sharded database has exactly one exchange step: every rank scans its
-contiguous shard of database rows for all queries, the (idx, d1, d2) triples are all-gathered
-(RCCL when the process group is "nccl"), and every rank folds them with orbx_knn2_merge_device.
+contiguous shard of database rows for all queries into one packed 16-byte record per query
+({int32 d1, d2; int64 idx}, orbx_knn2_hit), ONE all-gather moves every rank's nq records (RCCL when the
+process group is "nccl"), and every rank folds them with orbx_knn2_merge_packed_device.
 The fold is exact: the two smallest distances of the whole database lie inside the union of the
 per-shard best two, and shards are folded in row order so the lowest row index wins ties, as in
 the sequential scan of my_orb_slam2/src/ORBmatcher.cc:204-229.
+Scan, collective and fold are ordered on the device by events; the host never waits in between.
 """
 import torch
 import torch.distributed as dist
@@ -37,17 +39,34 @@ def frames_of_rank(nframes, rank, world):
     return list(range(int(rank), int(nframes), int(world)))
 
 
-def all_gather_partials(idx, d1, d2, group=None):
-    """All-gather per-shard results -> (world, nq) tensors, shard order = rank order."""
+def pack_hits(idx, d1, d2):
+    """(nq,) int64 / int32 / int32 -> (nq, 2) int64 records with the layout of orbx_knn2_hit
+    (little endian: d1 in the low half of word 0, d2 in the high half, idx in word 1)."""
+    w0 = (d1.to(torch.int64) & 0xFFFFFFFF) | (d2.to(torch.int64) << 32)
+    return torch.stack((w0, idx.to(torch.int64)), dim=1).contiguous()
+
+
+def unpack_hits(hits):
+    """Inverse of pack_hits for (..., 2) int64 records -> idx, d1, d2."""
+    w0 = hits[..., 0]
+    d1 = ((w0 << 32) >> 32).to(torch.int32)
+    d2 = (w0 >> 32).to(torch.int32)
+    return hits[..., 1].contiguous(), d1, d2
+
+
+def all_gather_hits(hits, group=None):
+    """One all-gather of every rank's (nq, 2) int64 records -> (world, nq, 2), shard order = rank order.
+    With a backend that cannot move device memory (gloo rehearsals) the records are staged through the host."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        return idx[None], d1[None], d2[None]
-    outs = []
-    for t in (idx, d1, d2):
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t.contiguous(), group=group)
-        outs.append(torch.stack(parts))
-    return tuple(outs)
+        return hits[None]
+    backend = dist.get_backend(group)
+    src = hits.contiguous()
+    if src.is_cuda and backend != "nccl":
+        src = src.cpu()
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)            # rank r's records at rows [r * nq, (r + 1) * nq)
+    return out.view((world,) + tuple(src.shape)).to(hits.device)
 
 
 class ShardedHammingMatcher:
@@ -60,16 +79,23 @@ class ShardedHammingMatcher:
         self.base = int(index_base)
         self.group = group
 
-    def knn2(self, d_query, init=256):
+    def knn2(self, d_query, init=256, slice_rows=None):
+        """-> (idx, d1, d2) of the scan over the whole database, on every rank. Returns without waiting for the
+        device; the results are ordered behind torch's current stream. slice_rows: queries per kernel launch
+        (None = all at once)."""
         nq = d_query.shape[0]
         dev = d_query.device
-        idx = torch.empty(nq, dtype=torch.int64, device=dev)
-        d1 = torch.empty(nq, dtype=torch.int32, device=dev)
-        d2 = torch.empty(nq, dtype=torch.int32, device=dev)
-        self.m.knn2_device(d_query, self.db, idx, d1, d2, init=init, index_base=self.base)
-        self.m.synchronize()
-        gi, g1, g2 = all_gather_partials(idx, d1, d2, self.group)
-        o_idx, o_d1, o_d2 = torch.empty_like(idx), torch.empty_like(d1), torch.empty_like(d2)
-        self.m.merge_device(gi.contiguous(), g1.contiguous(), g2.contiguous(), o_idx, o_d1, o_d2, init=init)
-        self.m.synchronize()
+        hits = torch.empty((nq, 2), dtype=torch.int64, device=dev)
+        step = nq if not slice_rows else int(slice_rows)
+        for s0 in range(0, nq, step):
+            s1 = min(nq, s0 + step)
+            self.m.knn2_packed_device(d_query[s0:s1], self.db, hits[s0:s1], init=init, index_base=self.base)
+        self.m.after()                                   # the collective starts after the scan (device-side order)
+        gathered = all_gather_hits(hits, self.group)     # ONE collective of nq * 16 bytes per rank
+        world = gathered.shape[0]
+        o_idx = torch.empty(nq, dtype=torch.int64, device=dev)
+        o_d1 = torch.empty(nq, dtype=torch.int32, device=dev)
+        o_d2 = torch.empty(nq, dtype=torch.int32, device=dev)
+        self.m.merge_packed_device(gathered, world, o_idx, o_d1, o_d2, init=init)
+        self.m.after()
         return o_idx, o_d1, o_d2

@@ -181,3 +181,76 @@ def test_compute_stereo_matches_full():
         assert kept == int((our >= 0).sum())
         total += kept
     assert total > 400
+
+
+@pytest.mark.parametrize("nshards", [1, 2, 3, 8])
+def test_packed_scan_and_merge_of_simulated_ranks(nshards):
+    """The sharded-database path without a process group: every "rank" scans its contiguous shard into packed
+    16-byte records, the records are laid out as one all-gather would leave them ([rank][query]) and the
+    product's device-side fold must give the oracle's scan of the whole database, ties and duplicates included."""
+    import torch
+    from my_orb_slam2_amd import sharding
+    rng = np.random.default_rng(100 + nshards)
+    q, db = planted(rng, 700, 9001)
+    db[8000] = db[17]                      # duplicates in different shards: the lowest row must win
+    db[4500] = db[17]
+    q[0] = db[17]
+    q[1] = db[8000]
+    q[1, 3] ^= 4
+    hm = m.HammingMatcher()
+    dq, ddb = torch.from_numpy(q).cuda(), torch.from_numpy(db).cuda()
+    bounds = sharding.shard_bounds(len(db), nshards)
+    for init in (256, 2**31 - 1):
+        gathered = torch.empty((nshards, len(q), 2), dtype=torch.int64, device="cuda")
+        for r in range(nshards):
+            hm.knn2_packed_device(dq, ddb[bounds[r]:bounds[r + 1]], gathered[r], init=init, index_base=bounds[r])
+        oi, o1, o2 = orc.knn2(q, db, init=init)
+        # the packed records of one shard carry the three-array result of the same scan
+        idx = torch.empty(len(q), dtype=torch.int64, device="cuda")
+        d1 = torch.empty(len(q), dtype=torch.int32, device="cuda")
+        d2 = torch.empty(len(q), dtype=torch.int32, device="cuda")
+        hm.knn2_device(dq, ddb[bounds[0]:bounds[1]], idx, d1, d2, init=init, index_base=bounds[0])
+        hm.synchronize()
+        pi, p1, p2 = sharding.unpack_hits(gathered[0])
+        assert torch.equal(pi, idx) and torch.equal(p1, d1) and torch.equal(p2, d2)
+        assert torch.equal(sharding.pack_hits(idx, d1, d2), gathered[0])
+        hm.merge_packed_device(gathered, nshards, idx, d1, d2, init=init)
+        hm.synchronize()
+        assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(d1.cpu().numpy(), o1)
+        assert np.array_equal(d2.cpu().numpy(), o2)
+
+
+def _sharded_worker(rank, world, port, q_np, db_np, out_dir):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from my_orb_slam2_amd import sharding
+    lo, hi = sharding.shard_range(len(db_np), rank, world)
+    sm = sharding.ShardedHammingMatcher(torch.from_numpy(db_np[lo:hi]).cuda(), lo, device=0)
+    idx, d1, d2 = sm.knn2(torch.from_numpy(q_np).cuda(), slice_rows=300)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), idx=idx.cpu().numpy(), d1=d1.cpu().numpy(), d2=d2.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_matcher_two_processes_one_gpu(tmp_path):
+    """ShardedHammingMatcher end to end with a real process group: two ranks share this box's one GPU (gloo
+    moves the records, staged through the host; on a multi-GPU node the same code runs over RCCL)."""
+    import socket
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(5)
+    q, db = planted(rng, 1000, 20001)
+    db[15000] = db[3]
+    q[0] = db[3]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_worker, args=(2, port, q, db, str(tmp_path)), nprocs=2, join=True)
+    oi, o1, o2 = orc.knn2(q, db)
+    for r in range(2):
+        z = np.load(str(tmp_path / ("r%d.npz" % r)))
+        assert np.array_equal(z["idx"], oi) and np.array_equal(z["d1"], o1) and np.array_equal(z["d2"], o2)

@@ -1,7 +1,8 @@
 """World-size-2 rehearsal of the multi-GPU paths on CPU (gloo): frame ownership needs no collective;
-the sharded kNN exchanges one (idx, d1, d2) triple per query and rank.  Per-shard scans come from the
-oracle here (no GPU in this test); the exchange goes through the product's all_gather_partials and the
-merged result must equal the oracle's scan of the whole database."""
+the sharded kNN exchanges one packed 16-byte record per query and rank in ONE all-gather.  Per-shard scans
+come from the oracle here (no GPU in this test); the records are packed, gathered and unpacked by the
+product's sharding module and the merged result must equal the oracle's scan of the whole database.  The
+product's device-side fold of the gathered layout is covered by tests/test_gpu_match.py."""
 import os
 import socket
 
@@ -46,8 +47,12 @@ def _worker(rank, world, port, q_np, db_np):
     lo, hi = sharding.shard_range(len(db_np), rank, world)
     idx, d1, d2 = orc.knn2(q_np, db_np[lo:hi])
     idx = np.where(idx >= 0, idx.astype(np.int64) + lo, -1)
-    gi, g1, g2 = sharding.all_gather_partials(torch.from_numpy(idx), torch.from_numpy(d1), torch.from_numpy(d2))
-    assert gi.shape == (world, len(q_np))
+    hits = sharding.pack_hits(torch.from_numpy(idx), torch.from_numpy(d1), torch.from_numpy(d2))
+    assert hits.shape == (len(q_np), 2) and hits.numpy().tobytes()[:16] == (
+        np.int32(d1[0]).tobytes() + np.int32(d2[0]).tobytes() + np.int64(idx[0]).tobytes())   # orbx_knn2_hit layout
+    gathered = sharding.all_gather_hits(hits)                     # one collective
+    assert gathered.shape == (world, len(q_np), 2)
+    gi, g1, g2 = sharding.unpack_hits(gathered)
     bi, b1, b2 = fold(gi.numpy(), g1.numpy(), g2.numpy(), 256)
     oi, o1, o2 = orc.knn2(q_np, db_np)
     ok = np.array_equal(bi, oi) and np.array_equal(b1, o1) and np.array_equal(b2, o2)

@@ -139,7 +139,7 @@ def main():
                                           % (world * shard, shard), "n_gpus": world,
                               "value": nq * world * shard * steps / dt, "unit": "Hamming pairs/s",
                               "ms_per_step": round(dt / steps * 1e3, 3),
-                              "collective": "all_gather of 3 x nq int per rank" if world > 1 else "none"}))
+                              "collective": "one all_gather of nq x 16 B per rank" if world > 1 else "none"}))
     if world > 1 and dist.is_initialized():
         dist.destroy_process_group()
 

@@ -103,7 +103,7 @@ def main():
     import torch
     import torch.distributed as dist
     import my_orb_slam2_amd as m
-    from my_orb_slam2_amd.sharding import shard_bounds, all_gather_partials
+    from my_orb_slam2_amd.sharding import shard_bounds, all_gather_hits, pack_hits
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,9 +140,9 @@ def main():
     li, l1, l2 = (torch.empty(nq, dtype=t.dtype, device=dev) for t in (pi, p1, p2))
     hm.merge_device(pi, p1, p2, li, l1, l2)
     hm.synchronize()
-    gi, g1, g2 = all_gather_partials(li, l1, l2)
+    gathered = all_gather_hits(pack_hits(li, l1, l2))          # one collective of nq * 16 bytes per rank
     idx, d1, d2 = torch.empty_like(li), torch.empty_like(l1), torch.empty_like(l2)
-    hm.merge_device(gi.contiguous(), g1.contiguous(), g2.contiguous(), idx, d1, d2)
+    hm.merge_packed_device(gathered, gathered.shape[0], idx, d1, d2)
     acc = torch.empty(nq, dtype=torch.uint8, device=dev)
     hm.ratio_test_device(d1, d2, acc, th=50, inclusive=True, ratio=0.6)
     hm.synchronize()
@@ -188,7 +188,7 @@ def main():
         print(json.dumps({"workload": "configs[4] full size: %d queries x %d database rows, %d shards, top-2 + merge + "
                                       "ratio test" % (nq, a.ndb, nshards),
                           "n_gpus": world, "seconds": round(dt, 2), "value": nq * a.ndb / dt, "unit": "Hamming pairs/s",
-                          "collective": "all_gather of 3 x nq int per rank" if world > 1 else "none (one GPU walks the shards)",
+                          "collective": "one all_gather of nq x 16 B per rank" if world > 1 else "none (one GPU walks the shards)",
                           "checks": st}, indent=1))
     if world > 1:
         dist.destroy_process_group()
