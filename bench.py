@@ -1,31 +1,35 @@
 #!/usr/bin/env python3
 """Throughput of the ORB front end on MI355X.
 
-Workload (BASELINE.json configs[1]): a synthetic batch of 752x480 uint8 frames, ORB extract+describe
-with nFeatures 1000, 8 levels, scale 1.2, FAST 20/7.  One "step" = one batch of --batch frames that
-already sits in HBM through the whole hot path (pyramid, FAST cells, quadtree, orientation + BRIEF);
-outputs stay on the device.  N > 1: one process per GPU, every rank extracts its own frames, no
-data-path collective ("scaling": "weak").
+Headline workload (BASELINE.json configs[1]): a synthetic batch of 4096 752x480 uint8 frames, ORB
+extract+describe with nFeatures 1000, 8 levels, scale 1.2, FAST 20/7.  One "step" = one pass over that batch
+(16 batched launches of 256 frames each, 1024 distinct frames cycled) that already sits in HBM, through the whole
+hot path (pyramid, FAST cells, quadtree, orientation + BRIEF); outputs stay on the device.  N > 1: one process per
+GPU, every rank extracts its own frames, no data-path collective ("scaling": "weak").
 
-    python bench.py --gpus 1 --steps 256 --warmup 16
+    python bench.py --gpus N --steps K --warmup W       # N > 1: starts N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  `roofline` is for the kernel that takes most of a step, timed with HIP
-events on the library's launch stream; `cpu_baseline` times the CPU oracle (a port of the reference's
-algorithm; the reference itself needs OpenCV 4 and cannot be built here) on the host cores.
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel that takes most of a step, timed with HIP events on
+the library's launch stream; `cpu_baseline` times the CPU oracle (a port of the reference's algorithm; the
+reference itself needs OpenCV 4 and cannot be built here) on the host cores.  The other BASELINE configs ride
+along as extra keys of the same line, each timed the same way (barrier + device synchronisation either side,
+maximum over ranks): `hd1080` (configs[3], frame-parallel), `stereo` (configs[2], pair-parallel, extraction x2 +
+the whole of Frame::ComputeStereoMatches) and `hamming` (configs[4]: 1 M queries against a 100 M row database
+split over the ranks, ONE all-gather of 16 bytes per query and rank, exact fold, ratio test).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (spec)
 W, H, NFEAT, NLEV, SCALE, INI, MINTH = 752, 480, 1000, 8, 1.2, 20, 7
@@ -41,23 +45,69 @@ STAGE_BYTES = {
     "octree": 4 * 10000 + 4 * 1000,                     # ~10k packed candidates in, ~1k selected out
     "orient_desc": 1000 * (43 * 43 + 60),               # one 43x43 patch per keypoint + its outputs
 }
+LEGS = ("hd1080", "stereo", "hamming")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step and GPU")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="frames per batched launch")
+    ap.add_argument("--launches", type=int, default=16, help="batched launches per step (16 x 256 = 4096 frames)")
     ap.add_argument("--unique", type=int, default=1024, help="distinct synthetic frames per GPU (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--no-hamming", action="store_true")
+    ap.add_argument("--legs", default=",".join(LEGS),
+                    help="comma-separated extra workloads out of hd1080,stereo,hamming ('' = none)")
+    ap.add_argument("--no-hamming", action="store_true", help="same as leaving hamming out of --legs")
+    ap.add_argument("--knn-nq", type=int, default=1_000_000)
+    ap.add_argument("--knn-ndb", type=int, default=100_000_000)
     ap.add_argument("--contexts", type=int, default=3,
-                    help="extractor contexts (HIP streams) a GPU alternates between; the tail of one step's "
-                         "kernels overlaps the head of the next step's")
+                    help="extractor contexts (HIP streams) a GPU alternates between; the tail of one launch's "
+                         "kernels overlaps the head of the next one's")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend; gloo is for rehearsals on a box without one GPU per rank")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses device 0 (needs --backend gloo)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher / process-group rehearsal without a GPU: no kernels run, value is null")
     return ap.parse_args()
 
+
+# ---- launcher: `python bench.py --gpus N` without torchrun -----------------------------------------------------
+
+def launch_ranks(a):
+    """Starts a.gpus fresh rank processes (this process has not touched torch or HIP) and waits for them. Rank 0
+    writes the result line to this process's stdout. Returns the exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    pending = set(range(a.gpus))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                for o in pending:
+                    procs[o].terminate()        # the exact processes started above
+        time.sleep(0.05)
+    return rc
+
+
+# ---- CPU baselines ----------------------------------------------------------------------------------------------
 
 def cpu_baseline(seconds, frames):
     """Frames/s of the CPU oracle, one frame per thread (the reference's unit of parallelism is one
@@ -93,38 +143,6 @@ def cpu_baseline(seconds, frames):
                       "(oracle/liborb_oracle.so, g++ -O3)" % (len(frames), sum(done), seconds, cores)}
 
 
-def hamming_bench(torch, device):
-    """Secondary metric: brute-force Hamming top-2, 65536 queries x 4M database rows on one GPU."""
-    import my_orb_slam2_amd as m
-    nq, ndb = 65536, 4 * 1024 * 1024
-    g = torch.Generator(device="cuda").manual_seed(1)
-    db = torch.randint(0, 256, (ndb, 32), dtype=torch.uint8, device="cuda", generator=g)
-    q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device="cuda", generator=g)
-    q[: nq // 2] = db[torch.randint(0, ndb, (nq // 2,), device="cuda", generator=g)]
-    idx = torch.empty(nq, dtype=torch.int64, device="cuda")
-    d1 = torch.empty(nq, dtype=torch.int32, device="cuda")
-    d2 = torch.empty(nq, dtype=torch.int32, device="cuda")
-    hm = m.HammingMatcher(device)
-    hm.knn2_device(q, db, idx, d1, d2)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        hm.knn2_device(q, db, idx, d1, d2)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    pairs = nq * ndb / dt
-    # VALU bound: 8 v_xor + 8 v_bcnt per pair. Integer VALU issues one wave64 instruction per SIMD every
-    # 4 cycles (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.0), i.e. 64 lanes/clk/CU:
-    # 256 CUs x 64 lanes x 2.4 GHz = 39.3e12 lane-ops/s, 16 of them per pair.
-    peak = 256 * 64 * 2.4e9 / 16
-    assert int((d1[: nq // 2] == 0).sum()) == nq // 2
-    out = {"metric": "Hamming pairs/s (top-2 kNN, 65536 x 4194304, 1 GPU)", "value": pairs,
-           "ms": dt * 1e3, "valu_peak_pairs_per_s": peak, "frac_of_valu_peak": pairs / peak}
-    out["cpu_baseline"] = hamming_cpu_baseline(q[:4096].cpu().numpy(), db[: 1 << 20].cpu().numpy())
-    return out
-
-
 def hamming_cpu_baseline(q, db, seconds=2.0):
     """The same top-2 scan by the CPU oracle on a bounded sample: the reference's SWAR bit count
     (src/ORBmatcher.cc:1705-1711) on one core, hardware popcount on one core and on all host threads used."""
@@ -153,111 +171,320 @@ def hamming_cpu_baseline(q, db, seconds=2.0):
             "sample": "blocks of %d queries x %d database rows for %.0f s per figure" % (chunk, len(db), seconds)}
 
 
-def main():
-    a = parse()
+# ---- one rank ---------------------------------------------------------------------------------------------------
+
+class Rank:
+    def __init__(self, a):
+        self.a = a
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+        # ORBX_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (rehearsal on a one-GPU box)
+        self.use_dist = self.world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"
+
+    def init_group(self):
+        import torch
+        import torch.distributed as dist
+        if not self.use_dist or dist.is_initialized():
+            return
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        kw = {}
+        if self.a.backend == "nccl":
+            kw["device_id"] = torch.device("cuda", self.local)
+        dist.init_process_group(self.a.backend, rank=self.rank, world_size=self.world, **kw)
+
+    def fence(self):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if self.use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        import torch
+        import torch.distributed as dist
+        if not self.use_dist:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if self.a.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn, steps, warmup):
+        """warmup untimed steps, then exactly `steps` steps between two fences; maximum over ranks, in seconds."""
+        for i in range(warmup):
+            fn(i)
+        self.fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        self.fence()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+
+class ExtractLeg:
+    """Frame-parallel extraction: `nctx` contexts alternate over batched launches of B frames."""
+
+    def __init__(self, R, width, height, nfeat, B, unique, nctx):
+        import torch
+        import my_orb_slam2_amd as m
+        self.R, self.B, self.nctx = R, B, nctx
+        self.unique = max(B, (unique + B - 1) // B * B)
+        self.host = m.synth_batch(R.rank * self.unique, self.unique, width, height)
+        self.frames = torch.from_numpy(self.host).cuda()
+        self.exs = [m.ORBextractor(nfeat, SCALE, NLEV, INI, MINTH, device=R.local, max_width=width,
+                                   max_height=height, max_batch=B) for _ in range(nctx)]
+        cap = self.exs[0].capacity
+        self.outs = [(torch.empty((B, cap, 7), dtype=torch.float32, device="cuda"),
+                      torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                      torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(nctx)]
+        self.nbatches = self.unique // B
+
+    def launch(self, i):
+        b = i % self.nbatches
+        k, d, c = self.outs[i % self.nctx]
+        self.exs[i % self.nctx].extract_batch_device(self.frames[b * self.B:(b + 1) * self.B], k, d, c)
+
+    def mean_keypoints(self):
+        return float(self.outs[0][2].float().mean().item())
+
+
+class StereoLeg:
+    """configs[2]: left + right extraction (nFeatures 1200) and Frame::ComputeStereoMatches, pair p on rank p mod G."""
+
+    def __init__(self, R, B=128, sets=2):
+        import torch
+        import my_orb_slam2_amd as m
+        self.B = B
+        self.left = torch.from_numpy(m.synth_batch(R.rank * B, B, W, H)).cuda()
+        self.right = torch.from_numpy(m.synth_batch(R.rank * B, B, W, H, right_view=True)).cuda()
+        self.bf, self.b = 47.90639384423901, 47.90639384423901 / 435.2046959714599   # EuRoC stereo: Camera.bf, bf / fx
+        self.sets = []
+        for _ in range(sets):
+            exl = m.ORBextractor(1200, SCALE, NLEV, INI, MINTH, device=R.local, max_width=W, max_height=H, max_batch=B)
+            exr = m.ORBextractor(1200, SCALE, NLEV, INI, MINTH, device=R.local, max_width=W, max_height=H, max_batch=B)
+            cap = exl.capacity
+
+            def alloc():
+                return (torch.empty((B, cap, 7), dtype=torch.float32, device="cuda"),
+                        torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                        torch.zeros(B, dtype=torch.int32, device="cuda"))
+            self.sets.append(dict(exl=exl, exr=exr, L=alloc(), R=alloc(), hm=m.HammingMatcher(R.local),
+                                  ur=torch.empty((B, cap), dtype=torch.float32, device="cuda"),
+                                  z=torch.empty((B, cap), dtype=torch.float32, device="cuda")))
+
+    def step(self, i):
+        s = self.sets[i % len(self.sets)]
+        s["exl"].extract_batch_device(self.left, *s["L"])
+        s["exr"].extract_batch_device(self.right, *s["R"])
+        # no host synchronisation: the call orders the three streams on the device (events)
+        s["hm"].compute_stereo_matches_device(s["exl"], s["exr"], *s["L"], *s["R"], self.bf, self.b, s["ur"], s["z"])
+
+    def finish(self):
+        for s in self.sets:
+            s["hm"].synchronize()
+
+
+def hamming_leg(R, a):
+    """configs[4]: nq queries against an ndb-row database split into contiguous shards, one per rank; every rank
+    scans its shard for all queries, ONE all-gather of 16 bytes per query and rank, exact fold, ratio test.
+    Size-independent checks: every planted query comes back with its row and distance, the ratio test accepts
+    exactly the planted queries, and a few queries are recomputed over the whole database with plain torch ops."""
     import torch
     import torch.distributed as dist
-    import my_orb_slam2_amd as m
+    from my_orb_slam2_amd import sharding, synth
+    nq, ndb = a.knn_nq, a.knn_ndb
+    dev = torch.device("cuda", R.local)
+    lo, hi = sharding.shard_range(ndb, R.rank, R.world)
+    db = synth.knn_db_rows(lo, hi - lo, dev)
+    q, src, planted = synth.knn_queries(nq, ndb, dev)
+    sm = sharding.ShardedHammingMatcher(db, lo, device=R.local)
+    acc = torch.empty(nq, dtype=torch.uint8, device=dev)
+    res = []
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    # Native libraries write to file descriptor 1 on their own (RCCL prints a version banner when its first
+    def step(i):
+        idx, d1, d2 = sm.knn2(q, slice_rows=131072)
+        sm.m.ratio_test_device(d1, d2, acc, th=50, inclusive=True, ratio=0.6)
+        sm.m.after()
+        res[:] = [idx, d1, d2]
+    sm.knn2(q[:4096])                  # scratch buffers and the communicator come up outside the timed region
+    dt = R.timed(step, 1, 0)
+    idx, d1, d2 = res
+    half = nq // 2
+    st = {"planted_queries": half,
+          "planted_idx_wrong": int((idx[:half] != src).sum().item()),
+          "planted_d1_wrong": int((d1[:half] != planted).sum().item()),
+          "accepted": int(acc.sum().item()),
+          "accepted_not_planted": int(acc[half:].sum().item()),
+          "d1_gt_d2": int((d1 > d2).sum().item())}
+    ns = 8
+    picks = [(i * (nq // ns) + (i % 2) * half) % nq for i in range(ns)]      # planted and uniform ones alternate
+    wrong = 0
+    for qi in picks:
+        kt = torch.tensor(synth.knn_top2_torch(q[qi], db, lo), dtype=torch.int64)
+        if R.use_dist:
+            kt = kt.cuda() if a.backend == "nccl" else kt
+            allk = [torch.empty_like(kt) for _ in range(R.world)]
+            dist.all_gather(allk, kt)
+            kt = torch.sort(torch.cat(allk).cpu()).values[:2]
+        k1, k2 = int(kt[0]), int(kt[1])
+        got = (int(idx[qi].item()), int(d1[qi].item()), int(d2[qi].item()))
+        wrong += got != (k1 & ((1 << 40) - 1), k1 >> 40, k2 >> 40)
+    st["sampled_queries"], st["sampled_wrong"] = ns, wrong
+    bad = (st["planted_idx_wrong"] + st["planted_d1_wrong"] + st["accepted_not_planted"] + st["d1_gt_d2"] + wrong +
+           (st["accepted"] != half))
+    if bad:
+        raise SystemExit("bench.py: kNN property checks failed: %s" % json.dumps(st))
+    pairs = nq * ndb / dt
+    # VALU bound: 8 v_xor + 8 v_bcnt per pair. A wave64 VALU instruction occupies its SIMD for 4 cycles (measured:
+    # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.0), i.e. 64 lanes/clk/CU: 256 CUs x 64 lanes x 2.4 GHz per GPU.
+    peak = R.world * 256 * 64 * 2.4e9 / 16
+    out = {"metric": "Hamming pairs/s (top-2 kNN + ratio test, %d x %d, database sharded over %d GPU%s)"
+                     % (nq, ndb, R.world, "" if R.world == 1 else "s"),
+           "value": pairs, "seconds": round(dt, 3), "n_gpus": R.world, "scaling": "strong",
+           "rows_per_gpu": hi - lo, "collective": "one all_gather of nq x 16 B per rank" if R.world > 1 else "none",
+           "valu_peak_pairs_per_s": peak, "frac_of_valu_peak": round(pairs / peak, 4), "checks": st}
+    if R.rank == 0 and R.world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = hamming_cpu_baseline(q[:4096].cpu().numpy(), db[: 1 << 20].cpu().numpy())
+    return out
+
+
+def rehearse(R, a, real_stdout):
+    """No GPU: brings the ranks up, runs the collectives the timed path uses and prints a line without a value."""
+    import torch
+    import torch.distributed as dist
+    R.use_dist = True
+    R.a.backend = "gloo"
+    R.init_group()
+    dist.barrier()
+    t = torch.tensor([float(R.rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranks = dist.get_world_size()
+    if R.rank == 0:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps({"metric": "ORB frames/s (752x480, 8 lvl, 1000 kp)", "value": None, "unit": "frames/s",
+                          "n_gpus": R.world, "ranks_in_group": ranks, "backend": "gloo", "rehearsal": True,
+                          "max_rank_seen": int(t.item())}), flush=True)
+        os.dup2(2, 1)
+    dist.destroy_process_group()
+
+
+def run_rank(a):
+    R = Rank(a)
+    # Native libraries write to file descriptor 1 on their own (RCCL and gloo print a banner when their first
     # communicator comes up): until the result line, everything that goes to fd 1 is sent to stderr instead.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if a.rehearse:
+        return rehearse(R, a, real_stdout)
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
-    torch.cuda.set_device(local)
-    # ORBX_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (rehearsal on a one-GPU box)
-    use_dist = world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"
+    torch.cuda.set_device(R.local)
+    legs = [l for l in a.legs.split(",") if l]
+    for l in legs:
+        if l not in LEGS:
+            raise SystemExit("unknown leg %r" % l)
+    if a.no_hamming and "hamming" in legs:
+        legs.remove("hamming")
     B = a.batch
-    unique = max(B, (a.unique + B - 1) // B * B)
-
-    # ---- inputs: distinct frames per rank, resident in HBM before the clock starts ----
-    host = m.synth_batch(rank * unique, unique, W, H)
-    d_frames = torch.from_numpy(host).cuda()
-    nbatches = unique // B
     nctx = max(1, a.contexts)
-    exs = [m.ORBextractor(NFEAT, SCALE, NLEV, INI, MINTH, device=local, max_width=W, max_height=H, max_batch=B)
-           for _ in range(nctx)]
-    ex = exs[0]
-    cap = ex.capacity
-    # The process group comes up after the extractor contexts: their streams are created first and get hardware
-    # queues of their own (the box runs four per process); RCCL's streams, idle during the timed region, share.
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    outs = [(torch.empty((B, cap, 7), dtype=torch.float32, device="cuda"),
-             torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda"),
-             torch.zeros(B, dtype=torch.int32, device="cuda")) for _ in range(nctx)]
-    d_cnt = outs[0][2]
+
+    # ---- every workload's contexts come up before the process group: their streams are created first and get
+    # hardware queues of their own (the box runs four per process); RCCL's streams, idle while extraction runs,
+    # share ----
+    main = ExtractLeg(R, W, H, NFEAT, B, a.unique, nctx)
+    hd = ExtractLeg(R, 1920, 1080, 2000, 64, 64, nctx) if "hd1080" in legs else None
+    stereo = StereoLeg(R) if "stereo" in legs else None
+    R.init_group()
+    ranks_in_group = dist.get_world_size() if R.use_dist else 1
+
+    # ---- headline: exactly a.steps steps of a.launches batched launches each ----
+    L = a.launches
 
     def step(i):
-        b = i % nbatches
-        k, d, c = outs[i % nctx]
-        exs[i % nctx].extract_batch_device(d_frames[b * B:(b + 1) * B], k, d, c)
-
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(a.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kp_mean = float(d_cnt.float().mean().item())
+        for j in range(L):
+            main.launch(i * L + j)
+    for i in range(max(8, 2 * nctx)):                   # clocks and caches up before anything is counted
+        main.launch(i)
+    dt = R.timed(step, a.steps, a.warmup)
+    kp_mean = main.mean_keypoints()
 
     # ---- per-stage kernel time, HIP events on the library's launch stream (outside the timed region) ----
+    ex = main.exs[0]
     ex.set_profiling(True)
     acc = {}
     reps = 8
     for i in range(reps):
-        step(nctx * i)                      # context 0 only, so stages do not overlap another step
+        main.launch(nctx * i)               # context 0 only, so stages do not overlap another launch
         for k, v in ex.stage_ms().items():
             acc[k] = acc.get(k, 0.0) + v / reps
     ex.set_profiling(False)
 
-    if rank != 0:
-        if use_dist:
+    extra = {}
+    if hd is not None:
+        hsteps = 48
+        hdt = R.timed(hd.launch, hsteps, 6)
+        extra["hd1080"] = {"workload": "configs[3]: synthetic 1920x1080 frames, nFeatures 2000, 8 levels, frame-parallel",
+                           "value": round(R.world * hd.B * hsteps / hdt, 1), "unit": "frames/s", "n_gpus": R.world,
+                           "frames_per_launch_per_gpu": hd.B, "launches": hsteps, "scaling": "weak",
+                           "ms_per_launch": round(hdt / hsteps * 1e3, 3), "collective": "none",
+                           "mean_keypoints_per_frame": round(hd.mean_keypoints(), 1)}
+    if stereo is not None:
+        ssteps = 48
+        sdt = R.timed(stereo.step, ssteps, 6)
+        stereo.finish()
+        matched = float((stereo.sets[0]["ur"] >= 0).sum().item()) / stereo.B
+        extra["stereo"] = {"workload": "configs[2]: stereo pairs 752x480, nFeatures 1200, left + right extraction + "
+                                       "Frame::ComputeStereoMatches, pair p on rank p mod G",
+                           "value": round(R.world * stereo.B * ssteps / sdt, 1), "unit": "stereo pairs/s",
+                           "n_gpus": R.world, "pairs_per_launch_per_gpu": stereo.B, "launches": ssteps,
+                           "scaling": "weak", "ms_per_launch": round(sdt / ssteps * 1e3, 3), "collective": "none",
+                           "mean_stereo_matches_per_pair": round(matched, 1)}
+    host64 = main.host[:64]
+    del main, hd, stereo
+    torch.cuda.empty_cache()
+    if "hamming" in legs:
+        extra["hamming"] = hamming_leg(R, a)
+
+    if R.rank != 0:
+        if R.use_dist:
             dist.destroy_process_group()
         return
-    fps = world * B * a.steps / dt
+    world = R.world
+    frames_per_step = B * L
+    fps = world * frames_per_step * a.steps / dt
     dom = max(acc, key=acc.get)
     dom_bytes = STAGE_BYTES[dom] * B
     achieved = dom_bytes / (acc[dom] * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    # HBM traffic and VALU instruction counts of the same kernels come from rocprofv3 PMC passes of this program run
+    # by the builder (tools/profile_gpu.sh); they are static files, not measured by this run, and tagged as such.
+    traffic = valu = None
+    tpath, vpath = os.path.join(ROOT, "profiles", "traffic.json"), os.path.join(ROOT, "profiles", "valu.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(dom)
-    # what actually bounds the kernel (profiles/valu.json, from the PMC passes of tools/profile_gpu.sh):
-    # wave64 VALU instructions x 4 issue cycles per SIMD against the kernel's cycles
-    vpath = os.path.join(ROOT, "profiles", "valu.json")
-    valu = json.load(open(vpath)).get(dom) if os.path.exists(vpath) else None
+    if os.path.exists(vpath):
+        valu = json.load(open(vpath)).get(dom)
+    pmc_source = "profiles/traffic.json + profiles/valu.json: builder-run rocprofv3 --pmc passes, not measured by this run"
     out = {
         "metric": "ORB frames/s (752x480, 8 lvl, 1000 kp)",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "configs[1]: synthetic batch of 752x480 uint8 frames, ORB extract+describe, "
+        "config": {"workload": "configs[1]: synthetic batch of 4096 752x480 uint8 frames, ORB extract+describe, "
                                "nFeatures=1000, 8 levels, scale 1.2, FAST 20/7",
-                   "frames_per_step_per_gpu": B, "distinct_frames_per_gpu": unique,
+                   "frames_per_step_per_gpu": frames_per_step, "launches_per_step": L, "frames_per_launch": B,
+                   "distinct_frames_per_gpu": a.unique,
                    "mean_keypoints_per_frame": round(kp_mean, 1), "inputs": "resident in HBM",
-                   "contexts_per_gpu": nctx, "blur_taps": "CV_4_0_0", "quadtree_tie_break": "creation order"},
+                   "contexts_per_gpu": nctx, "blur_taps": "CV_4_0_0", "quadtree_tie_break": "creation order",
+                   "ranks_in_group": ranks_in_group, "backend": a.backend if R.use_dist else "none"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "traffic_source": pmc_source if traffic is not None else None,
                      "algorithmic_bytes_per_launch": dom_bytes,
                      "kernel_ms": round(acc[dom], 4),
                      "valu_issue": valu,
@@ -274,19 +501,27 @@ def main():
         out["roofline_valu"] = {"bound": "valu-issue", "kernel": dom, "achieved": round(issue_rate / 1e9, 2),
                                 "peak": round(issue_peak / 1e9, 2), "unit": "G wave64-instructions/s",
                                 "frac": round(issue_rate / issue_peak, 4),
-                                "frac_of_kernel_cycles": valu["valu_issue_frac"]}
+                                "frac_of_kernel_cycles": valu["valu_issue_frac"],
+                                "instruction_count_source": pmc_source}
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, host[:64])
+        out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, host64)
         out["gpu_over_cpu_all_cores"] = round(fps / out["cpu_baseline"]["value"], 1)
-    if world == 1 and not a.no_hamming:
-        h = hamming_bench(torch, local)
-        out["hamming"] = {k: (round(v, 4) if isinstance(v, float) and v < 1e6 else v) for k, v in h.items()}
+    for k, v in extra.items():
+        out[k] = {kk: (round(vv, 4) if isinstance(vv, float) and vv < 1e6 else vv) for kk, vv in v.items()}
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)
-    if use_dist:
+    if R.use_dist:
         os.dup2(2, 1)
         dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Nothing in this process has touched torch or HIP yet: start the ranks as children and report their fate.
+        sys.exit(launch_ranks(a))
+    run_rank(a)
 
 
 if __name__ == "__main__":
