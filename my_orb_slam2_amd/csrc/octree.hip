@@ -153,7 +153,8 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
             __syncthreads();
             for (int i = t; i < Lc; i += kThreads)
                 if (cur.cnt[i] > 1) { rank[i] -= 1; order[rank[i]] = i; }
-        } else {
+        } else if (P >= (1 << 20)) {
+            // (a node could hold more points than the packed keys below have bits for: compare count and position)
             if (t == 0) sh[1] = 0;
             __syncthreads();
             for (int i = t; i < Lc; i += kThreads) {
@@ -164,6 +165,32 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
                         const int cj = cur.cnt[j];
                         r += (cj > 1 && (cj > ci || (cj == ci && j < i))) ? 1 : 0;
                     }
+                    rank[i] = r;
+                    order[r] = i;
+                    atomicAdd(&sh[1], 1);
+                }
+            }
+        } else {
+            // Rank = number of split candidates with a larger key, key = count << 12 | (4095 - list position): more
+            // points first, list order among equals. Keys sit in LDS (sinc is free until the ranks are known), padded
+            // with zeros to a multiple of four so that they are read four at a time, every lane the same address.
+            unsigned* key = reinterpret_cast<unsigned*>(sinc);
+            const int Lc4 = (Lc + 3) & ~3;
+            if (t == 0) sh[1] = 0;
+            for (int i = t; i < Lc4; i += kThreads) {
+                const int ci = i < Lc ? cur.cnt[i] : 0;
+                key[i] = ci > 1 ? ((unsigned)ci << 12) | (unsigned)(4095 - i) : 0u;
+            }
+            __syncthreads();
+            for (int i0 = 0; i0 < Lc; i0 += kThreads) {
+                const int i = i0 + t;
+                const unsigned ki = i < Lc ? key[i] : 0u;
+                int r = 0;
+                for (int j = 0; j < Lc4; j += 4) {
+                    const uint4 k4 = *reinterpret_cast<const uint4*>(key + j);
+                    r += (k4.x > ki) + (k4.y > ki) + (k4.z > ki) + (k4.w > ki);
+                }
+                if (ki != 0u) {
                     rank[i] = r;
                     order[r] = i;
                     atomicAdd(&sh[1], 1);

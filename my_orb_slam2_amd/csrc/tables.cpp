@@ -138,6 +138,7 @@ bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g,
         return false;
     }
     g.maxTileBytes = g.tilePitch * ((maxHCell + 6 + 39) / 40 * 40);   // fast_cells stages rows in batches of 40
+    g.nodeCap = (g.nodeCap + 3) & ~3;         // the quadtree reads node keys four at a time
     g.totalCells = cells;
     g.totalSlots = slots;
     g.totalSel = sel;
