@@ -1,0 +1,424 @@
+"""CPU tests: second statements for the stages of the oracle that had none.
+
+Each function below restates one routine of One-sixth/my_orb_slam2 in plain Python, following the control
+flow of the cited lines one step at a time (lists instead of std::list, numpy float32 where the C++ code
+computes in float), independently of oracle/orb_oracle.cpp.  The oracle must agree with them on the synthetic
+frames.  The reference ships no fixture for these stages; what is compared here is two readings of the same
+source lines, written at different times in different languages.  Paths are relative to my_orb_slam2/.
+"""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import my_orb_slam2_amd as m
+from tests import oracle as orc
+
+F = np.float32
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cv_round(v):
+    """cvRound: nearest integer, ties to even."""
+    return int(np.rint(F(v)))
+
+
+# ---------------------------------------------------------------- DistributeOctTree
+class Node:
+    """ExtractorNode (include/ORBextractor.h:33-44)."""
+    seq = 0
+
+    def __init__(self):
+        self.UL = self.UR = self.BL = self.BR = (0, 0)
+        self.keys = []
+        self.no_more = False
+        Node.seq += 1
+        self.id = Node.seq                      # stands in for the node's address in the sort at :676
+
+    def divide(self):
+        """ExtractorNode::DivideNode (src/ORBextractor.cc:473-529)."""
+        half_x = int(math.ceil(F(self.UR[0] - self.UL[0]) / F(2)))
+        half_y = int(math.ceil(F(self.BR[1] - self.UL[1]) / F(2)))
+        n1, n2, n3, n4 = Node(), Node(), Node(), Node()
+        n1.UL = self.UL
+        n1.UR = (self.UL[0] + half_x, self.UL[1])
+        n1.BL = (self.UL[0], self.UL[1] + half_y)
+        n1.BR = (self.UL[0] + half_x, self.UL[1] + half_y)
+        n2.UL, n2.UR, n2.BL, n2.BR = n1.UR, self.UR, n1.BR, (self.UR[0], self.UL[1] + half_y)
+        n3.UL, n3.UR, n3.BL, n3.BR = n1.BL, n1.BR, self.BL, (n1.BR[0], self.BL[1])
+        n4.UL, n4.UR, n4.BL, n4.BR = n3.UR, n2.BR, n3.BR, self.BR
+        for kp in self.keys:
+            if kp[0] < n1.UR[0]:
+                (n1 if kp[1] < n1.BR[1] else n3).keys.append(kp)
+            elif kp[1] < n1.BR[1]:
+                n2.keys.append(kp)
+            else:
+                n4.keys.append(kp)
+        for n in (n1, n2, n3, n4):
+            if len(n.keys) == 1:
+                n.no_more = True
+        return n1, n2, n3, n4
+
+
+def py_distribute_octree(keys, min_x, max_x, min_y, max_y, N):
+    """ORBextractor::DistributeOctTree (src/ORBextractor.cc:531-755). keys: list of (x, y, response) with float
+    coordinates. The node address in the pair sort of :676 is replaced by the creation number of the node (the
+    choice every implementation of this repository makes; the address is not reproducible)."""
+    n_ini = int(math.floor(F(max_x - min_x) / F(max_y - min_y) + F(0.5)))          # round(), :535
+    h_x = F(max_x - min_x) / F(n_ini)                                                # :537
+    nodes = []                                                                       # lNodes, front = index 0
+    ini = []
+    for i in range(n_ini):                                                           # :544-555
+        ni = Node()
+        ni.UL = (int(h_x * F(i)), 0)
+        ni.UR = (int(h_x * F(i + 1)), 0)
+        ni.BL = (ni.UL[0], max_y - min_y)
+        ni.BR = (ni.UR[0], max_y - min_y)
+        nodes.append(ni)
+        ini.append(ni)
+    for kp in keys:                                                                  # :558-562
+        ini[int(F(kp[0]) / h_x)].keys.append(kp)
+    kept = []
+    for n in nodes:                                                                  # :566-577
+        if len(n.keys) == 1:
+            n.no_more = True
+            kept.append(n)
+        elif len(n.keys) > 0:
+            kept.append(n)
+    nodes = kept
+
+    def add_children(children, size_and_node, count):
+        nonlocal nodes
+        for c in children:                                                           # :613-652 / :683-718
+            if len(c.keys) > 0:
+                nodes.insert(0, c)
+                if len(c.keys) > 1:
+                    count[0] += 1
+                    size_and_node.append((len(c.keys), c.id, c))
+
+    finish = False
+    size_and_node = []
+    while not finish:                                                                # :586
+        prev_size = len(nodes)
+        to_expand = [0]
+        size_and_node = []
+        i = 0
+        while i < len(nodes):                                                        # :598-657
+            n = nodes[i]
+            if n.no_more:
+                i += 1
+                continue
+            children = n.divide()
+            before = len(nodes)
+            add_children(children, size_and_node, to_expand)
+            i += len(nodes) - before                                                 # the node moved back by the pushes
+            del nodes[i]                                                             # erase, lit = next
+        if len(nodes) >= N or len(nodes) == prev_size:                               # :661
+            finish = True
+        elif len(nodes) + to_expand[0] * 3 > N:                                      # :665
+            while not finish:
+                prev_size = len(nodes)
+                prev = size_and_node
+                size_and_node = []
+                prev.sort(key=lambda p: (p[0], p[1]))                                # :676
+                for j in range(len(prev) - 1, -1, -1):                               # :677
+                    n = prev[j][2]
+                    children = n.divide()
+                    add_children(children, size_and_node, [0])
+                    nodes.remove(n)                                                  # :720
+                    if len(nodes) >= N:                                              # :722
+                        break
+                if len(nodes) >= N or len(nodes) == prev_size:                       # :726
+                    finish = True
+    out = []
+    for n in nodes:                                                                  # :736-752
+        best = n.keys[0]
+        for kp in n.keys[1:]:
+            if kp[2] > best[2]:
+                best = kp
+        out.append(best)
+    return out
+
+
+def check_octree(cand, w, h, quota):
+    """cand: candidates as the oracle hands them to DistributeOctTree (coordinates relative to the 16-px border)."""
+    min_b, max_bx, max_by = 16, w - 16, h - 16                                       # :765-768
+    want = py_distribute_octree([(float(p["x"]), float(p["y"]), float(p["response"])) for p in cand],
+                                min_b, max_bx, min_b, max_by, quota)
+    got = orc.distribute_octree(cand, min_b, max_bx, min_b, max_by, quota)
+    assert [(p["x"], p["y"], p["response"]) for p in got] == [(F(a), F(b), F(c)) for a, b, c in want]
+    return len(want)
+
+
+def test_octree_against_the_python_transcription_on_frames():
+    total = 0
+    for nf, idx in ((1000, 0), (1000, 5), (300, 2), (2000, 3), (40, 1)):
+        ex = orc.Extractor(nf)
+        ex.extract(m.synth_frame(idx))
+        quotas = ex.features_per_level()
+        for l in range(8):
+            w, h = ex.level_size(l)
+            cand = ex.level_candidates(l)
+            n = check_octree(cand, w, h, int(quotas[l]))
+            # the extractor's own selection is the same list with the border added (:826-839)
+            sel = ex.level_selected(l)
+            assert len(sel) == n
+            total += n
+    assert total > 4000
+
+
+def test_octree_against_the_python_transcription_on_random_sets():
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        w, h = int(rng.integers(120, 900)), int(rng.integers(100, 500))
+        if round((w - 32) / (h - 32)) < 1:
+            continue
+        n = int(rng.choice([0, 1, 2, 3, 7, 50, 400, 2500]))
+        N = int(rng.choice([0, 1, 2, 5, 17, 60, 217, 700]))
+        pts = set()
+        clustered = trial % 3 == 0
+        while len(pts) < n:
+            if clustered:
+                x, y = int(rng.normal((w - 38) / 3, 9)), int(rng.normal((h - 38) / 2, 6))
+            else:
+                x, y = int(rng.integers(3, w - 35)), int(rng.integers(3, h - 35))
+            if 3 <= x < w - 35 and 3 <= y < h - 35:
+                pts.add((x, y))
+        cand = np.zeros(n, orc.KP)
+        # cells row-major, rows inside a cell: the order the extractor produces
+        for i, (x, y) in enumerate(sorted(pts, key=lambda p: (p[1] // 31, p[0] // 31, p[1], p[0]))):
+            cand[i] = (x, y, 7, -1, int(rng.integers(7, 40)), 0, -1)            # few distinct responses: ties
+        check_octree(cand, w, h, N)
+
+
+# ---------------------------------------------------------------- IC_Angle
+def py_fast_atan2(y, x):
+    """cv::fastAtan2 of OpenCV 4.0 (atan_f32 polynomial), float32 throughout."""
+    y, x = F(y), F(x)
+    k = F(180.0 / math.pi)
+    p1, p3, p5, p7 = (F(0.9997878412794807) * k, F(-0.3258083974640975) * k, F(0.1555786518463281) * k,
+                      F(-0.04432655554792128) * k)
+    ax, ay = abs(x), abs(y)
+    eps = F(2.220446049250313e-16)
+    if ax >= ay:
+        c = ay / (ax + eps)
+        c2 = c * c
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    else:
+        c = ax / (ay + eps)
+        c2 = c * c
+        a = F(90) - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    if x < 0:
+        a = F(180) - a
+    if y < 0:
+        a = F(360) - a
+    return F(a)
+
+
+def py_ic_angle(image, x, y, umax):
+    """IC_Angle (src/ORBextractor.cc:69-96) on a level with its 19-px border (image[y + 19][x + 19])."""
+    cy, cx = cv_round(y) + 19, cv_round(x) + 19
+    m_01 = m_10 = 0
+    for u in range(-15, 16):
+        m_10 += u * int(image[cy, cx + u])
+    for v in range(1, 16):
+        v_sum = 0
+        d = int(umax[v])
+        for u in range(-d, d + 1):
+            val_plus, val_minus = int(image[cy + v, cx + u]), int(image[cy - v, cx + u])
+            v_sum += val_plus - val_minus
+            m_10 += u * (val_plus + val_minus)
+        m_01 += v * v_sum
+    return py_fast_atan2(F(m_01), F(m_10))
+
+
+def test_ic_angle_against_the_python_transcription():
+    ex = orc.Extractor()
+    checked = 0
+    with np.errstate(over="ignore"):
+        for idx in (0, 9):
+            ex.extract(m.synth_frame(idx))
+            umax = ex.umax()
+            for l in (0, 1, 4, 7):
+                img = ex.level_image(l, padded=True)
+                sel = ex.level_selected(l)
+                for p in sel[::3]:
+                    assert p["angle"] == py_ic_angle(img, p["x"], p["y"], umax), (idx, l, p)
+                    checked += 1
+    assert checked > 300
+
+
+# ---------------------------------------------------------------- computeOrbDescriptor
+def load_pattern():
+    text = open(os.path.join(ROOT, "include", "orbx_pattern31.inc")).read()
+    text = re.sub(r"/\*.*?\*/|//[^\n]*", " ", text, flags=re.S)                   # the header comment holds digits too
+    v = [int(t) for t in re.findall(r"-?\d+", text)]
+    assert len(v) == 1024
+    return np.array(v, np.int32).reshape(512, 2)                  # cv::Point pattern[512] (:440-442)
+
+
+def py_orb_descriptor(blurred, x, y, angle_deg, pattern):
+    """computeOrbDescriptor (src/ORBextractor.cc:99-139). cos / sin are taken correctly rounded to float (the
+    oracle's default; the reference calls the float overloads of its C runtime)."""
+    factor_pi = F(math.pi / F(180.0))
+    angle = F(angle_deg) * factor_pi
+    a, b = F(math.cos(float(angle))), F(math.sin(float(angle)))
+    cy, cx = cv_round(y), cv_round(x)
+    desc = np.zeros(32, np.uint8)
+
+    def value(i):
+        px, py = F(pattern[i, 0]), F(pattern[i, 1])
+        return int(blurred[cy + cv_round(px * b + py * a), cx + cv_round(px * a - py * b)])
+    for i in range(32):
+        val = 0
+        for k in range(8):
+            t0, t1 = value(16 * i + 2 * k), value(16 * i + 2 * k + 1)
+            val |= (1 if t0 < t1 else 0) << k
+        desc[i] = val
+    return desc
+
+
+def test_descriptors_against_the_python_transcription():
+    pattern = load_pattern()
+    assert tuple(pattern[0]) == (8, -3) and tuple(pattern[1]) == (9, 5)              # first pair of :144
+    checked = 0
+    for blur in (orc.BLUR_CV_4_0_0, orc.BLUR_CV_4_2_PLUS):
+        ex = orc.Extractor(blur=blur)
+        kps, desc = ex.extract(m.synth_frame(4))
+        first = 0
+        for l in range(8):
+            sel = ex.level_selected(l)
+            bl = ex.level_blurred(l)
+            assert bl is not None or len(sel) == 0
+            # the blurred level is GaussianBlur of the level (:1077-1078)
+            if bl is not None:
+                assert np.array_equal(bl, orc.gaussian7(ex.level_image(l), blur))
+            for j in range(0, len(sel), 5):
+                p = sel[j]
+                want = py_orb_descriptor(bl, p["x"], p["y"], p["angle"], pattern)
+                assert np.array_equal(desc[first + j], want), (l, j)
+                checked += 1
+            # operator() scales the coordinates after the descriptors, above level 0 only (:1087-1093)
+            s = ex.scale_factors()[0][l]
+            out = kps[first:first + len(sel)]
+            assert np.array_equal(out["x"], sel["x"] * s if l else sel["x"])
+            assert np.array_equal(out["angle"], sel["angle"]) and np.all(out["octave"] == l)
+            first += len(sel)
+        assert first == len(kps)
+    assert checked > 300
+
+
+# ---------------------------------------------------------------- Frame::ComputeStereoMatches
+def py_compute_stereo_matches(kl, dl, kr, dr, pyr_l, pyr_r, scale, inv_scale, bf, b):
+    """Frame::ComputeStereoMatches (src/Frame.cc:503-677). pyr_l / pyr_r: the levels of the two pyramids (no
+    border). Returns mvuRight, mvDepth."""
+    TH_HIGH, TH_LOW = 100, 50
+    N = len(kl)
+    u_right = np.full(N, -1.0, np.float32)
+    depth = np.full(N, -1.0, np.float32)
+    th_orb = (TH_HIGH + TH_LOW) // 2
+    n_rows = pyr_l[0].shape[0]
+    rows = [[] for _ in range(n_rows)]
+    for i_r in range(len(kr)):                                                       # :520-530
+        kp_y = F(kr[i_r]["y"])
+        r = F(2.0) * F(scale[kr[i_r]["octave"]])
+        maxr, minr = int(math.ceil(kp_y + r)), int(math.floor(kp_y - r))
+        for yi in range(minr, maxr + 1):
+            rows[yi].append(i_r)
+    min_z = F(b)
+    min_d = F(0)
+    max_d = F(bf) / min_z
+    dist_idx = []
+    for i_l in range(N):                                                             # :541
+        level_l = int(kl[i_l]["octave"])
+        v_l, u_l = F(kl[i_l]["y"]), F(kl[i_l]["x"])
+        cands = rows[int(v_l)]
+        if not cands:
+            continue
+        min_u, max_u = u_l - max_d, u_l - min_d
+        if max_u < 0:
+            continue
+        best_dist, best_idx = TH_HIGH, 0
+        for i_r in cands:                                                            # :565-586
+            oct_r = int(kr[i_r]["octave"])
+            if oct_r < level_l - 1 or oct_r > level_l + 1:
+                continue
+            u_r = F(kr[i_r]["x"])
+            if min_u <= u_r <= max_u:
+                dist = int(np.unpackbits(dl[i_l] ^ dr[i_r]).sum())
+                if dist < best_dist:
+                    best_dist, best_idx = dist, i_r
+        if best_dist >= th_orb:                                                      # :589
+            continue
+        u_r0 = F(kr[best_idx]["x"])
+        sf = F(inv_scale[level_l])
+
+        def c_round(v):                                                              # round(): half away from zero
+            return F(math.floor(abs(float(v)) + 0.5) * (1 if v >= 0 else -1))
+        scaled_ul, scaled_vl, scaled_ur0 = c_round(u_l * sf), c_round(v_l * sf), c_round(u_r0 * sf)
+        w = 5
+        left, right = pyr_l[level_l].astype(np.float32), pyr_r[level_l].astype(np.float32)
+        yl, xl = int(scaled_vl), int(scaled_ul)
+        IL = left[yl - w:yl + w + 1, xl - w:xl + w + 1]                              # :600-602
+        IL = IL - IL[w, w]
+        best_sad, best_inc = 2 ** 31 - 1, 0
+        L = 5
+        dists = [F(0)] * (2 * L + 1)
+        iniu, endu = scaled_ur0 + F(L - w), scaled_ur0 + F(L + w + 1)
+        if iniu < 0 or endu >= right.shape[1]:                                       # :612
+            continue
+        for inc in range(-L, L + 1):                                                 # :615-629
+            xr = int(scaled_ur0 + F(inc))
+            IR = right[yl - w:yl + w + 1, xr - w:xr + w + 1]
+            IR = IR - IR[w, w]
+            dist = F(np.abs(IL - IR).sum())
+            if dist < best_sad:
+                best_sad, best_inc = int(dist), inc
+            dists[L + inc] = dist
+        if best_inc == -L or best_inc == L:                                          # :631
+            continue
+        d1, d2, d3 = dists[L + best_inc - 1], dists[L + best_inc], dists[L + best_inc + 1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            delta = (d1 - d3) / (F(2.0) * (d1 + d3 - F(2.0) * d2))                   # :639
+        if delta < -1 or delta > 1:                        # :641 (a NaN passes this test and fails the one at :649)
+            continue
+        best_ur = F(scale[level_l]) * (scaled_ur0 + F(best_inc) + delta)             # :645
+        disparity = u_l - best_ur
+        if min_d <= disparity < max_d:                                               # :649
+            if disparity <= 0:
+                disparity = F(0.01)
+                best_ur = F(float(u_l) - 0.01)
+            depth[i_l] = F(bf) / disparity
+            u_right[i_l] = best_ur
+            dist_idx.append((best_sad, i_l))
+    dist_idx.sort()                                                                  # :663
+    if dist_idx:
+        median = F(dist_idx[len(dist_idx) // 2][0])
+        th_dist = F(1.5) * F(1.4) * median
+        for d, i in reversed(dist_idx):                                              # :667-676
+            if F(d) < th_dist:
+                break
+            u_right[i] = -1
+            depth[i] = -1
+    return u_right, depth
+
+
+def test_compute_stereo_matches_against_the_python_transcription():
+    bf = 47.90639384423901
+    b = bf / 435.2046959714599
+    matched = 0
+    for idx in (0, 6):
+        exl, exr = orc.Extractor(1200), orc.Extractor(1200)
+        kl, dl = exl.extract(m.synth_frame(idx))
+        kr, dr = exr.extract(m.synth_frame(idx, right_view=True))
+        ur, z, kept = orc.compute_stereo_matches(exl, exr, kl, dl, kr, dr, bf, b)
+        scale, inv = exl.scale_factors()[0], exl.scale_factors()[1]
+        pl = [exl.level_image(l) for l in range(8)]
+        pr = [exr.level_image(l) for l in range(8)]
+        want_ur, want_z = py_compute_stereo_matches(kl, dl, kr, dr, pl, pr, scale, inv, F(bf), F(b))
+        assert np.array_equal(ur, want_ur) and np.array_equal(z, want_z)
+        assert kept == int((want_ur >= 0).sum())
+        matched += kept
+    assert matched > 200
