@@ -142,11 +142,22 @@ int orbx_get_stage_ms(orbx_ctx* ctx, float* ms);
 int orbx_level_size(const orbx_ctx* ctx, int level, int* width, int* height);
 int orbx_get_level(orbx_ctx* ctx, int frame, int level, int border, uint8_t* dst, size_t dst_stride);
 
-/* Stage probes of the last call, for parity tests: the blurred level the descriptors sample
- * (src/ORBextractor.cc:1077-1078), the per-cell FAST candidates in vToDistributeKeys order
- * (:770-821, coordinates relative to the 16-px border) and the DistributeOctTree selection in
- * list order (:826-839, level coordinates, response set, angle -1). Host outputs. */
-int orbx_debug_blur_level(orbx_ctx* ctx, int frame, int level, uint8_t* dst, size_t dst_stride);
+/* Stage probes of the last call, for parity tests: the per-cell FAST candidates in vToDistributeKeys order
+ * (:770-821, coordinates relative to the 16-px border), the DistributeOctTree selection in
+ * list order (:826-839, level coordinates, response set, angle -1) and the blurred pixels the descriptors
+ * sample (GaussianBlur of the level, src/ORBextractor.cc:1077-1078). Host outputs.
+ * orbx_debug_keypoint_blur: the extractor blurs only the patch around each keypoint, inside the kernel that
+ * makes the descriptors; this probe re-runs that kernel on one frame of the last call and returns, for the
+ * frame's keypoints in output order, the patch exactly as the descriptor stage read it: ORBX_BLUR_PATCH_ROWS
+ * rows of ORBX_BLUR_PATCH_PITCH bytes per keypoint, the keypoint at row ORBX_BLUR_PATCH_CY, column
+ * ORBX_BLUR_PATCH_CX. Only offsets the rotated pattern can reach (within sqrt(338) + 1/2 pixel of the keypoint
+ * in both coordinates' unit boxes) hold blurred values; the rest is unspecified. *n = keypoints of the frame;
+ * at most cap patches are written. */
+#define ORBX_BLUR_PATCH_ROWS 37
+#define ORBX_BLUR_PATCH_PITCH 44
+#define ORBX_BLUR_PATCH_CY 18
+#define ORBX_BLUR_PATCH_CX 23
+int orbx_debug_keypoint_blur(orbx_ctx* ctx, int frame, uint8_t* dst, int cap, int* n);
 int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, orbx_keypoint* out, int cap, int* n);
 int orbx_debug_selected(orbx_ctx* ctx, int frame, int level, orbx_keypoint* out, int cap, int* n);
 

@@ -591,25 +591,40 @@ extern "C" int orbx_get_level(orbx_ctx* c, int frame, int level, int border, uin
     return ORBX_OK;
 }
 
-extern "C" int orbx_debug_blur_level(orbx_ctx* c, int frame, int level, uint8_t* dst, size_t dst_stride) {
-    int rc = check_probe(c, frame, level);
+extern "C" int orbx_debug_keypoint_blur(orbx_ctx* c, int frame, uint8_t* dst, int cap, int* n) {
+    int rc = check_probe(c, frame, 0);
     if (rc) return rc;
-    const LevelGeom& L = c->geom.lv[level];
-    if (!dst || L.w < 1 || L.h < 1) {
-        set_error("orbx_debug_blur_level: null destination or empty level");
+    if (!n || (!dst && cap > 0) || cap < 0) {
+        set_error("orbx_debug_keypoint_blur: bad argument");
         return ORBX_ERR_INVALID;
     }
-    const uint8_t* src;
-    size_t stride;
-    level_ptr(c, frame, level, &src, &stride);
+    // The orientation + descriptor kernel of the batched call runs once more on this frame alone, with its probe
+    // output switched on; keypoints and descriptors go to scratch arrays.
+    const PyramidGeom& g = c->geom;
+    const int kcap = orbx_keypoint_capacity(c);
+    const size_t patch = (size_t)kBlurPatchRows * kBlurPatchPitch;
+    FrameSet fs = c->fs;
+    fs.img += (size_t)frame * fs.imgFrameStride;
+    fs.pyr += (size_t)frame * g.pyrBytes;
+    fs.sel += (size_t)frame * g.totalSel;
+    fs.selCount += (size_t)frame * g.nlevels;
+    fs.selBefore += (size_t)frame * g.nlevels;
     uint8_t* tmp = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)L.w * L.h));
-    hipError_t e = launch_blur_level(src, L.w, L.h, (long long)stride, tmp, L.w, c->cfg.blur_taps, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    const size_t oDesc = up256((size_t)kcap * sizeof(orbx_keypoint)), oCnt = oDesc + up256((size_t)kcap * ORBX_DESC_BYTES),
+                 oDump = oCnt + 256, total = oDump + (size_t)kcap * patch;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&tmp), total));
+    int32_t count = 0;
+    hipError_t e = hipMemsetAsync(tmp + oDump, 0, (size_t)kcap * patch, c->stream);
     if (e == hipSuccess)
-        e = hipMemcpy2D(dst, dst_stride, tmp, (size_t)L.w, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost);
+        e = launch_orient_desc(fs, g, 1, c->cfg.blur_taps, reinterpret_cast<orbx_keypoint*>(tmp), tmp + oDesc, kcap,
+                               reinterpret_cast<int32_t*>(tmp + oCnt), c->stream, tmp + oDump);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(&count, tmp + oCnt, sizeof(count), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && count > 0 && cap > 0)
+        e = hipMemcpy(dst, tmp + oDump, (size_t)std::min(count, cap) * patch, hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
     HIP_TRY(e);
+    *n = count;
     return ORBX_OK;
 }
 

@@ -132,9 +132,12 @@ hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nfram
                              hipStream_t s);
 hipError_t launch_octree(const FrameSet& fs, const PyramidGeom& g, int nframes, hipStream_t s);
 hipError_t launch_orient_desc(const FrameSet& fs, const PyramidGeom& g, int nframes, int blurTaps,
-                              orbx_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, hipStream_t s);
-hipError_t launch_blur_level(const uint8_t* src, int w, int h, long long stride, uint8_t* dst,
-                             long long dstStride, int blurTaps, hipStream_t s);
+                              orbx_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, hipStream_t s,
+                              uint8_t* blDump = nullptr);
+// Shape of one keypoint's blurred patch in the probe output of launch_orient_desc (blDump): rows x row pitch, with
+// the keypoint at (row, column) = (kBlurPatchCy, kBlurPatchCx).
+constexpr int kBlurPatchRows = ORBX_BLUR_PATCH_ROWS, kBlurPatchPitch = ORBX_BLUR_PATCH_PITCH,
+              kBlurPatchCy = ORBX_BLUR_PATCH_CY, kBlurPatchCx = ORBX_BLUR_PATCH_CX;
 size_t octree_lds_bytes(const PyramidGeom& g);
 
 // Results go to idx / d1 / d2, or, when hits != nullptr, to nq packed orbx_knn2_hit records.

@@ -19,7 +19,7 @@
 //      for the odd one).
 // Only what the rotated pattern can reach is blurred: its points lie within radius sqrt(338) of the
 // keypoint, so the work items of both passes come from tables built at compile time for that disc.
-// orbx_debug_blur_level() runs the same arithmetic over a full level for parity tests.
+// orbx_debug_keypoint_blur() hands the blurred patches of one frame's keypoints to the parity tests.
 #include "orbx_internal.h"
 
 namespace orbx {
@@ -59,6 +59,8 @@ constexpr int kBlRows = 37;             // blurred rows: patch rows 3..39
 constexpr int kWavesPerBlock = 4;
 constexpr int kWaveLds = kRowsAlloc * kRPitch + kTPairs * kTDw * 4;  // 2112 + 3520 bytes
 constexpr int kHIters = 3, kVIters = 3; // 64-item rounds of the row pass and of the column pass
+static_assert(kBlRows == kBlurPatchRows && kTPitch == kBlurPatchPitch && kPR - 3 == kBlurPatchCy && kCx == kBlurPatchCx,
+              "the probe's patch shape is the kernel's");
 
 // Byte weights for the intensity-centroid sums, four columns per dword: patch row v + 15 (32, the last
 // one all zero) x dword q (8), column u = 4q - 15 + byte. .x: 1 inside the disc (plain row sum);
@@ -254,7 +256,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
                                                                            int blurTaps,
                                                                            orbx_keypoint* __restrict__ kpsOut,
                                                                            uint8_t* __restrict__ descOut, int cap,
-                                                                           int32_t* __restrict__ countsOut) {
+                                                                           int32_t* __restrict__ countsOut,
+                                                                           uint8_t* __restrict__ blDump) {
     __shared__ __attribute__((aligned(16))) uint8_t s_mem[kWavesPerBlock * kWaveLds];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the set-up scalar
@@ -415,6 +418,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
         }
     }
     wave_sync();
+    if (blDump) {
+        // parity probe: this keypoint's blurred patch as the descriptor stage reads it, kBlRows x kTPitch bytes
+        // (only the part the rotated pattern can reach has been computed)
+        uint8_t* out = blDump + ((long long)f * cap + outIdx) * (kBlRows * kTPitch);
+        for (int i = lane; i < kBlRows * kTPitch; i += 64) out[i] = R[i];
+    }
 
     // ---- steered BRIEF on the blurred patch (:99-139) ----
     const float rad = __fmul_rn(angle, (float)(3.14159265358979323846 / 180.f));
@@ -459,39 +468,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     }
 }
 
-// Full-level blur with the same arithmetic (parity probe for src/ORBextractor.cc:1078).
-__global__ __launch_bounds__(256) void blur_level_kernel(const uint8_t* __restrict__ src, int w, int h,
-                                                         long long stride, uint8_t* __restrict__ dst,
-                                                         long long dstStride, int blurTaps) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const int K0[7] = {18, 34, 49, 55, 49, 34, 18};
-    const int K1[7] = {18, 34, 48, 56, 48, 34, 18};
-    unsigned acc = 0;
-    for (int r = 0; r < 7; r++) {
-        const uint8_t* row = src + (long long)reflect101(y + r - 3, h) * stride;
-        unsigned hsum = 0;
-        for (int c = 0; c < 7; c++)
-            hsum += (unsigned)(blurTaps == ORBX_BLUR_CV_4_0_0 ? K0[c] : K1[c]) * row[reflect101(x + c - 3, w)];
-        acc += (unsigned)(blurTaps == ORBX_BLUR_CV_4_0_0 ? K0[r] : K1[r]) * min(hsum, 0xFFFFu);
-    }
-    dst[(long long)y * dstStride + x] = (uint8_t)min((acc + 32768u) >> 16, 255u);
-}
-
 hipError_t launch_orient_desc(const FrameSet& fs, const PyramidGeom& g, int nframes, int blurTaps,
-                              orbx_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, hipStream_t s) {
+                              orbx_keypoint* kps, uint8_t* desc, int cap, int32_t* counts, hipStream_t s,
+                              uint8_t* blDump) {
     // level 0 is read with dword loads like the other levels: the caller of this launcher has made it 4-byte aligned
     if ((uintptr_t)fs.img % 4 || fs.imgRowStride % 4 || fs.imgFrameStride % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sel_prefix_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, fs, g.nlevels, nframes, counts);
     dim3 grid(nframes, (g.totalSel + kWavesPerBlock - 1) / kWavesPerBlock, 1), block(64 * kWavesPerBlock, 1, 1);
-    hipLaunchKernelGGL(orient_desc_kernel, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts);
-    return hipGetLastError();
-}
-
-hipError_t launch_blur_level(const uint8_t* src, int w, int h, long long stride, uint8_t* dst,
-                             long long dstStride, int blurTaps, hipStream_t s) {
-    dim3 grid((w + 63) / 64, (h + 3) / 4, 1), block(256, 1, 1);
-    hipLaunchKernelGGL(blur_level_kernel, grid, block, 0, s, src, w, h, stride, dst, dstStride, blurTaps);
+    hipLaunchKernelGGL(orient_desc_kernel, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts, blDump);
     return hipGetLastError();
 }
 

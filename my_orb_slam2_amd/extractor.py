@@ -198,12 +198,18 @@ class ORBextractor:
         """Levels of frame 0 of the last call, without the 19-px border frame."""
         return [self.get_level(l) for l in range(self.nlevels)]
 
-    def debug_blur_level(self, level, frame=0):
-        w, h = self.level_size(level)
-        out = np.empty((h, w), dtype=np.uint8)
-        check(lib().orbx_debug_blur_level(self._ctx, frame, level, np_ptr(out), out.strides[0]),
-              "orbx_debug_blur_level")
-        return out
+    BLUR_PATCH_SHAPE = (37, 44)      # ORBX_BLUR_PATCH_ROWS x ORBX_BLUR_PATCH_PITCH
+    BLUR_PATCH_CENTRE = (18, 23)     # row, column of the keypoint inside its patch
+
+    def debug_keypoint_blur(self, frame=0):
+        """Blurred patch of every keypoint of `frame` of the last call, (N, 37, 44) uint8, as the descriptor
+        stage of the kernel read it (only offsets the rotated pattern can reach are defined)."""
+        n = C.c_int(0)
+        check(lib().orbx_debug_keypoint_blur(self._ctx, frame, None, 0, C.byref(n)), "orbx_debug_keypoint_blur")
+        out = np.zeros((max(n.value, 1),) + self.BLUR_PATCH_SHAPE, dtype=np.uint8)
+        check(lib().orbx_debug_keypoint_blur(self._ctx, frame, np_ptr(out), out.shape[0], C.byref(n)),
+              "orbx_debug_keypoint_blur")
+        return out[:n.value]
 
     def _probe(self, fn, level, frame):
         n = C.c_int(0)

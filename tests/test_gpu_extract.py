@@ -1,6 +1,6 @@
 """GPU parity tests: the HIP extractor (through the C ABI) against the CPU oracle, stage by stage.
 
-Bars: pyramid, blur, FAST candidate list and quadtree selection bit-exact (same values, same order);
+Bars: pyramid, blur (the patches the descriptor kernel blurs, not a separate probe kernel), FAST candidate list and quadtree selection bit-exact (same values, same order);
 angles within 1e-3 degree; descriptors bit-exact (per-bit mismatch rate reported, must be 0)."""
 import numpy as np
 import pytest
@@ -19,6 +19,51 @@ def make(nfeatures=1000, w=752, h=480, batch=1, blur=m.BLUR_CV_4_0_0, nlevels=8,
                          blur_taps=blur)
     cpu = orc.Extractor(nfeatures, scale, nlevels, ini, mn, blur)
     return gpu, cpu
+
+
+def reachable_mask():
+    """Offsets (dy, dx) from the keypoint that a rounded, rotated pattern point can land on: the farthest pattern
+    point is (-13, -13) (src/ORBextractor.cc:151), so real positions lie within sqrt(338) of the keypoint and
+    cvRound picks the offset whose unit box holds the position."""
+    rows, pitch = m.ORBextractor.BLUR_PATCH_SHAPE
+    cy, cx = m.ORBextractor.BLUR_PATCH_CENTRE
+    dy, dx = np.mgrid[0:rows, 0:pitch]
+    ny = np.maximum(2 * np.abs(dy - cy) - 1, 0)
+    nx = np.maximum(2 * np.abs(dx - cx) - 1, 0)
+    return nx * nx + ny * ny <= 4 * 338 + 2
+
+
+def check_hot_path_blur(gpu, cpu, frame=0):
+    """The blur the descriptors really sample: orient_desc_kernel blurs a patch per keypoint in LDS; its patches
+    must equal the oracle's GaussianBlur of the whole level (src/ORBextractor.cc:1077-1078) wherever the pattern
+    can reach."""
+    patches = gpu.debug_keypoint_blur(frame)
+    mask = reachable_mask()
+    rows, pitch = m.ORBextractor.BLUR_PATCH_SHAPE
+    cy, cx = m.ORBextractor.BLUR_PATCH_CENTRE
+    assert mask.sum() > 1000 and mask[cy - 18, cx] and mask[cy, cx + 18] and mask[cy + 13, cx - 13]
+    k = 0
+    for l in range(cpu.nlevels):
+        sel = cpu.level_selected(l)
+        cb = cpu.level_blurred(l)
+        assert cb is not None or len(sel) == 0
+        for p in sel:
+            x, y = int(p["x"]), int(p["y"])
+            want = cb[y - cy:y - cy + rows, x - cx:x - cx + pitch]
+            got = patches[k]
+            if want.shape != mask.shape:           # patch sticks out of the level: compare what lies inside
+                full = np.zeros(mask.shape, np.uint8)
+                inside = np.zeros(mask.shape, bool)
+                y0, x0 = max(0, cy - y), max(0, cx - x)
+                sub = cb[max(y - cy, 0):y - cy + rows, max(x - cx, 0):x - cx + pitch]
+                full[y0:y0 + sub.shape[0], x0:x0 + sub.shape[1]] = sub
+                inside[y0:y0 + sub.shape[0], x0:x0 + sub.shape[1]] = True
+                assert inside[mask].all()           # keypoints sit >= 19 px inside, the pattern reaches 18
+                want = full
+            assert np.array_equal(got[mask], want[mask]), "blurred patch of keypoint %d (level %d)" % (k, l)
+            k += 1
+    assert k == len(patches)
+    return k
 
 
 def compare_frame(gpu, cpu, img, frame_kps=None, frame_desc=None, stages=True):
@@ -44,9 +89,7 @@ def compare_frame(gpu, cpu, img, frame_kps=None, frame_desc=None, stages=True):
             assert len(gs) == len(cs), "selected count level %d: %d vs %d" % (l, len(gs), len(cs))
             for f in ("x", "y", "response", "octave", "size"):
                 assert np.array_equal(gs[f], cs[f]), "selected level %d field %s" % (l, f)
-            cb = cpu.level_blurred(l)
-            if cb is not None:
-                assert np.array_equal(gpu.debug_blur_level(l), cb), "blur level %d" % l
+        check_hot_path_blur(gpu, cpu)
     assert len(gk) == len(ck)
     for f in ("x", "y", "size", "response", "octave", "class_id"):
         assert np.array_equal(gk[f], ck[f]), f
