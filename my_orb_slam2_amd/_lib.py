@@ -88,6 +88,11 @@ SIGNATURES = {
     "orbx_search_for_initialization": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, C.c_float, C.c_float,
                                                  C.c_float, C.c_float, _P, C.c_int, C.c_float, C.c_int, _P,
                                                  C.POINTER(C.c_int)]),
+    "orbx_search_for_initialization_device": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_float,
+                                                        C.c_float, C.c_float, C.c_float, _P, C.c_int, C.c_float,
+                                                        C.c_int, _P, C.POINTER(C.c_int)]),
+    "orbx_search_by_bow_device": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int,
+                                            _P, _P, _P, C.c_int, C.c_float, C.c_int, _P, C.POINTER(C.c_int)]),
     "orbx_search_by_projection_frame": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P,
                                                   C.c_float, C.c_float, C.c_float, C.c_float, _P, C.c_int, C.c_float,
                                                   C.c_float, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_int)]),

@@ -1064,6 +1064,48 @@ extern "C" int orbx_undistort_assign_grid_device(orbx_matcher* m, int nframes, i
     return ORBX_OK;
 }
 
+namespace {
+// Argument checks and the walk over the two node lists, shared by both forms of orbx_search_by_bow.
+// Returns ORBX_OK with rows / npairs filled (possibly empty).
+int bow_prepare(const char* who, orbx_matcher* m, int mode, const void* keys1_un, const void* desc1,
+                const uint8_t* valid1, int n1, const uint32_t* fv1_nodes, const int32_t* fv1_start,
+                const uint32_t* fv1_items, int fv1_n, const void* keys2, const void* desc2, const uint8_t* valid2,
+                int n2, const uint32_t* fv2_nodes, const int32_t* fv2_start, const uint32_t* fv2_items, int fv2_n,
+                int32_t* matches, int* nmatches, std::vector<BowRow>& rows, long long& npairs) {
+    const bool kfkf = mode == ORBX_BOW_KEYFRAME_KEYFRAME;
+    if (!m || (mode != ORBX_BOW_KEYFRAME_FRAME && !kfkf) || n1 < 0 || n2 < 0 || fv1_n < 0 || fv2_n < 0 || !nmatches ||
+        (n1 > 0 && (!keys1_un || !desc1 || !valid1)) || (n2 > 0 && (!keys2 || !desc2 || (kfkf && !valid2))) ||
+        (fv1_n > 0 && (!fv1_nodes || !fv1_start || !fv1_items)) ||
+        (fv2_n > 0 && (!fv2_nodes || !fv2_start || !fv2_items)) || ((kfkf ? n1 : n2) > 0 && !matches)) {
+        set_error("%s: bad argument", who);
+        return ORBX_ERR_INVALID;
+    }
+    for (int j = 0; j + 1 < fv1_n; j++)
+        if (!(fv1_nodes[j] < fv1_nodes[j + 1])) { set_error("%s: fv1_nodes not ascending", who); return ORBX_ERR_INVALID; }
+    for (int j = 0; j + 1 < fv2_n; j++)
+        if (!(fv2_nodes[j] < fv2_nodes[j + 1])) { set_error("%s: fv2_nodes not ascending", who); return ORBX_ERR_INVALID; }
+    for (int side = 0; side < 2; side++) {
+        const int32_t* st = side ? fv2_start : fv1_start;
+        const int n = side ? fv2_n : fv1_n;
+        bool ok = n == 0 || st[0] == 0;
+        for (int j = 0; ok && j < n; j++) ok = st[j] <= st[j + 1];
+        if (!ok) {
+            set_error("%s: fv%d_start must rise from 0", who, side + 1);
+            return ORBX_ERR_INVALID;
+        }
+    }
+    *nmatches = 0;
+    const int nout = kfkf ? n1 : n2;
+    for (int i = 0; i < nout; i++) matches[i] = -1;
+    if (!build_bow_rows(fv1_nodes, fv1_start, fv1_items, fv1_n, valid1, n1, fv2_nodes, fv2_start, fv2_items, fv2_n, n2,
+                        rows, npairs)) {
+        set_error("%s: feature vector index out of range", who);
+        return ORBX_ERR_INVALID;
+    }
+    return ORBX_OK;
+}
+}  // namespace
+
 extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint* keys1_un, const uint8_t* desc1,
                                   const uint8_t* valid1, int n1, const uint32_t* fv1_nodes,
                                   const int32_t* fv1_start, const uint32_t* fv1_items, int fv1_n,
@@ -1071,38 +1113,12 @@ extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint
                                   const uint32_t* fv2_nodes, const int32_t* fv2_start, const uint32_t* fv2_items,
                                   int fv2_n, float nnratio, int check_orientation, int32_t* matches,
                                   int* nmatches) {
-    const bool kfkf = mode == ORBX_BOW_KEYFRAME_KEYFRAME;
-    if (!m || (mode != ORBX_BOW_KEYFRAME_FRAME && !kfkf) || n1 < 0 || n2 < 0 || fv1_n < 0 || fv2_n < 0 || !nmatches ||
-        (n1 > 0 && (!keys1_un || !desc1 || !valid1)) || (n2 > 0 && (!keys2 || !desc2 || (kfkf && !valid2))) ||
-        (fv1_n > 0 && (!fv1_nodes || !fv1_start || !fv1_items)) ||
-        (fv2_n > 0 && (!fv2_nodes || !fv2_start || !fv2_items)) || ((kfkf ? n1 : n2) > 0 && !matches)) {
-        set_error("orbx_search_by_bow: bad argument");
-        return ORBX_ERR_INVALID;
-    }
-    for (int j = 0; j + 1 < fv1_n; j++)
-        if (!(fv1_nodes[j] < fv1_nodes[j + 1])) { set_error("orbx_search_by_bow: fv1_nodes not ascending"); return ORBX_ERR_INVALID; }
-    for (int j = 0; j + 1 < fv2_n; j++)
-        if (!(fv2_nodes[j] < fv2_nodes[j + 1])) { set_error("orbx_search_by_bow: fv2_nodes not ascending"); return ORBX_ERR_INVALID; }
-    for (int side = 0; side < 2; side++) {
-        const int32_t* st = side ? fv2_start : fv1_start;
-        const int n = side ? fv2_n : fv1_n;
-        bool ok = n == 0 || st[0] == 0;
-        for (int j = 0; ok && j < n; j++) ok = st[j] <= st[j + 1];
-        if (!ok) {
-            set_error("orbx_search_by_bow: fv%d_start must rise from 0", side + 1);
-            return ORBX_ERR_INVALID;
-        }
-    }
-    *nmatches = 0;
-    const int nout = kfkf ? n1 : n2;
-    for (int i = 0; i < nout; i++) matches[i] = -1;
     std::vector<BowRow> rows;
     long long npairs = 0;
-    if (!build_bow_rows(fv1_nodes, fv1_start, fv1_items, fv1_n, valid1, n1, fv2_nodes, fv2_start, fv2_items, fv2_n, n2,
-                        rows, npairs)) {
-        set_error("orbx_search_by_bow: feature vector index out of range");
-        return ORBX_ERR_INVALID;
-    }
+    int rc = bow_prepare("orbx_search_by_bow", m, mode, keys1_un, desc1, valid1, n1, fv1_nodes, fv1_start, fv1_items,
+                         fv1_n, keys2, desc2, valid2, n2, fv2_nodes, fv2_start, fv2_items, fv2_n, matches, nmatches,
+                         rows, npairs);
+    if (rc) return rc;
     if (rows.empty() || npairs == 0) return ORBX_OK;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = m->stream;
@@ -1112,8 +1128,7 @@ extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint
     const size_t oD1 = 0, oD2 = oD1 + up(32 * (size_t)n1), oIt = oD2 + up(32 * (size_t)n2),
                  oRw = oIt + up(4 * (size_t)nItems2), oDs = oRw + up(sizeof(BowRow) * rows.size()),
                  total = oDs + up(2 * (size_t)npairs);
-    int rc = matcher_scratch(m, total, s);
-    if (rc) return rc;
+    if ((rc = matcher_scratch(m, total, s))) return rc;
     if ((rc = matcher_pinned(m, total))) return rc;
     uint8_t* base = static_cast<uint8_t*>(m->scratch);
     std::memcpy(m->pin + oD1, desc1, 32 * (size_t)n1);
@@ -1132,14 +1147,143 @@ extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint
     return ORBX_OK;
 }
 
+extern "C" int orbx_search_by_bow_device(orbx_matcher* m, int mode, const orbx_keypoint* keys1_un,
+                                         const uint8_t* d_desc1, const uint8_t* valid1, int n1,
+                                         const uint32_t* fv1_nodes, const int32_t* fv1_start,
+                                         const uint32_t* fv1_items, int fv1_n, const orbx_keypoint* keys2,
+                                         const uint8_t* d_desc2, const uint8_t* valid2, int n2,
+                                         const uint32_t* fv2_nodes, const int32_t* fv2_start,
+                                         const uint32_t* fv2_items, int fv2_n, float nnratio, int check_orientation,
+                                         int32_t* matches, int* nmatches) {
+    std::vector<BowRow> rows;
+    long long npairs = 0;
+    int rc = bow_prepare("orbx_search_by_bow_device", m, mode, keys1_un, d_desc1, valid1, n1, fv1_nodes, fv1_start,
+                         fv1_items, fv1_n, keys2, d_desc2, valid2, n2, fv2_nodes, fv2_start, fv2_items, fv2_n, matches,
+                         nmatches, rows, npairs);
+    if (rc) return rc;
+    if (((uintptr_t)d_desc1 % 16) || ((uintptr_t)d_desc2 % 16)) {
+        set_error("orbx_search_by_bow_device: descriptor arrays must be 16-byte aligned");
+        return ORBX_ERR_INVALID;
+    }
+    if (rows.empty() || npairs == 0) return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const int nItems2 = fv2_start[fv2_n];
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    // The descriptors are already in HBM. The kernel reads its rows and the right-hand feature lists from pinned
+    // host memory and writes the distance rows back into it: one launch and one wait, no copy either way.
+    const size_t oIt = 0, oRw = oIt + up(4 * (size_t)nItems2), oDs = oRw + up(sizeof(BowRow) * rows.size()),
+                 total = oDs + up(2 * (size_t)npairs);
+    if ((rc = matcher_pinned(m, total))) return rc;
+    std::memcpy(m->pin + oIt, fv2_items, 4 * (size_t)nItems2);
+    std::memcpy(m->pin + oRw, rows.data(), sizeof(BowRow) * rows.size());
+    HIP_TRY(launch_bow_distances((int)rows.size(), reinterpret_cast<const BowRow*>(m->pin + oRw), d_desc1,
+                                 reinterpret_cast<const uint32_t*>(m->pin + oIt), d_desc2,
+                                 reinterpret_cast<uint16_t*>(m->pin + oDs), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint16_t* dist = reinterpret_cast<const uint16_t*>(m->pin + oDs);
+    *nmatches = replay_search_by_bow(mode, rows, dist, fv2_items, keys1_un, keys2, valid2, n1, n2, nnratio,
+                                     check_orientation != 0, matches);
+    return ORBX_OK;
+}
+
 namespace {
-// Shared by the windowed searches: checks the grid, sends queries, descriptors, keypoints and grid of the searched
-// frame through the pinned staging buffer in one copy, runs the candidate kernel and brings the packed lists back.
-// On return head = {total, counts[n1], offsets[n1]} and the candidates sit at m->pin.
+inline size_t up256z(size_t v) { return (v + 255) / 256 * 256; }
+
+// Device-resident inputs of a windowed search.
+struct WindowDev {
+    const uint8_t* d1;              // descriptors of the queries
+    const orbx_keypoint* k2;        // searched frame: undistorted keypoints, descriptors, right coordinates, grid
+    const uint8_t* d2;
+    const float* uRight2;
+    const int32_t* cellStart;
+    const int32_t* cellItems;
+};
+
+// What window_search_core needs beyond its caller's own use of the two staging buffers.
+struct WindowCoreLayout {
+    int n1;
+    int budget;                     // candidate entries that come back without a second round trip
+    long long capTotal;             // bound of the whole list: every active query meets every listed keypoint
+    size_t pQ, pHd, pCd, pinBytes;  // offsets inside the pinned buffer (from the caller's first free byte)
+    size_t sCur, sCd, scratchBytes; // offsets inside the device scratch buffer
+    WindowCoreLayout(int n1_, long long capTotal_, size_t pinFree, size_t scratchFree) : n1(n1_), capTotal(capTotal_) {
+        budget = (int)std::min<long long>(capTotal, std::max<long long>(1 << 16, 64LL * n1));
+        pQ = up256z(pinFree);
+        pHd = pQ + up256z(sizeof(WindowQuery) * (size_t)n1);
+        pCd = pHd + up256z(4 * 2 * (size_t)n1);
+        pinBytes = pCd + 4 * (size_t)budget;
+        sCur = up256z(scratchFree);
+        sCd = sCur + 256;
+        scratchBytes = sCd + 4 * (size_t)capTotal;
+    }
+};
+
+// The candidate kernel and the way back of its lists. The kernel reads the queries from pinned host memory and
+// writes counts, offsets and (up to lay.budget) candidates straight into it, so the usual call is one launch and
+// one wait, with no copy either way. Only when the lists outgrow the budget does the kernel run again into the
+// device scratch region that holds any list, followed by a copy of what exists. The caller has sized both
+// buffers with lay (matcher_pinned / matcher_scratch) and may have queued uploads on the stream.
+// On return head = {counts[n1], offsets[n1]} and *candHost points at the packed lists.
+int window_search_core(orbx_matcher* m, const char* who, const std::vector<WindowQuery>& queries, const WindowDev& in,
+                       int n2, float min_x, float min_y, float max_x, float max_y, const WindowCoreLayout& lay,
+                       std::vector<int32_t>& head, const uint32_t** candHost) {
+    const int n1 = lay.n1;
+    hipStream_t s = m->stream;
+    uint8_t* base = static_cast<uint8_t*>(m->scratch);
+    std::memcpy(m->pin + lay.pQ, queries.data(), sizeof(WindowQuery) * (size_t)n1);
+    const float invW = static_cast<float>(ORBX_GRID_COLS) / (max_x - min_x);
+    const float invH = static_cast<float>(ORBX_GRID_ROWS) / (max_y - min_y);
+    int32_t* hd = reinterpret_cast<int32_t*>(m->pin + lay.pHd);
+    auto launch = [&](uint32_t* cand, int cap) {
+        return launch_window_candidates(n1, reinterpret_cast<const WindowQuery*>(m->pin + lay.pQ), in.d1, in.k2, in.d2,
+                                        in.uRight2, in.cellStart, in.cellItems, min_x, min_y, invW, invH, n2, cap,
+                                        reinterpret_cast<int32_t*>(base + lay.sCur), hd, hd + n1, cand, s);
+    };
+    HIP_TRY(launch(reinterpret_cast<uint32_t*>(m->pin + lay.pCd), lay.budget));
+    HIP_TRY(hipStreamSynchronize(s));
+    bool overflow = false;
+    for (int i = 0; i < n1; i++) overflow |= hd[i] < 0;
+    size_t ncand = 0;
+    if (overflow) {
+        HIP_TRY(launch(reinterpret_cast<uint32_t*>(base + lay.sCd), (int)lay.capTotal));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    // the header leaves the pinned buffer before the buffer may grow for a long candidate list
+    head.assign(hd, hd + 2 * (size_t)n1);
+    for (int i = 0; i < n1; i++) {
+        if (head[i] < 0 || head[n1 + i] < 0 || (long long)head[n1 + i] + head[i] > lay.capTotal) {
+            set_error("%s: inconsistent candidate lists", who);
+            return ORBX_ERR_STATE;
+        }
+        ncand = std::max(ncand, (size_t)head[n1 + i] + (size_t)head[i]);
+    }
+    if (!overflow) {
+        *candHost = reinterpret_cast<const uint32_t*>(m->pin + lay.pCd);
+        return ORBX_OK;
+    }
+    int rc = matcher_pinned(m, std::max<size_t>(4 * ncand, 4));
+    if (rc) return rc;
+    if (ncand > 0) {
+        HIP_TRY(hipMemcpyAsync(m->pin, base + lay.sCd, 4 * ncand, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    *candHost = reinterpret_cast<const uint32_t*>(m->pin);
+    return ORBX_OK;
+}
+
+long long window_cap_total(const std::vector<WindowQuery>& queries, int nItems) {
+    long long active = 0;
+    for (const WindowQuery& q : queries) active += q.r >= 0.0f;
+    return std::max(active * nItems, 1LL);
+}
+
+// Host-array form shared by the windowed searches: checks the grid, sends descriptors, keypoints and grid of the
+// searched frame through the pinned staging buffer in one copy, then runs window_search_core.
 int run_window_search(orbx_matcher* m, const char* who, const std::vector<WindowQuery>& queries, const uint8_t* desc1,
                       const orbx_keypoint* keys2, const uint8_t* desc2, const float* uright2, int n2,
                       const int32_t* cell_start2, const int32_t* cell_items2, float min_x, float min_y, float max_x,
-                      float max_y, std::vector<int32_t>& head) {
+                      float max_y, std::vector<int32_t>& head, const uint32_t** candHost) {
     const int n1 = (int)queries.size();
     const int kCells = ORBX_GRID_COLS * ORBX_GRID_ROWS;
     const int nItems = cell_start2[kCells];
@@ -1159,61 +1303,45 @@ int run_window_search(orbx_matcher* m, const char* who, const std::vector<Window
             return ORBX_ERR_INVALID;
         }
     }
-    // an active query can meet every keypoint of the grid at most: the bound of the packed candidate list
-    long long active = 0;
-    for (const WindowQuery& q : queries) active += q.r >= 0.0f;
-    if (n2 > 0x7FFFFF || active * nItems > 0x3FFFFFFF) {
+    const long long capTotal = window_cap_total(queries, nItems);
+    if (n2 > 0x7FFFFF || capTotal > 0x3FFFFFFF) {
         set_error("%s: too many keypoints (%d queries x %d)", who, n1, n2);
         return ORBX_ERR_INVALID;
     }
-    const int capTotal = (int)std::max(active * nItems, 1LL);
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = m->stream;
-    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     // inputs packed in pinned memory in the layout of the device scratch: one copy in
-    const size_t oQ = 0, oD1 = oQ + up(sizeof(WindowQuery) * n1), oK2 = oD1 + up(32 * (size_t)n1),
-                 oD2 = oK2 + up(sizeof(orbx_keypoint) * n2), oUr = oD2 + up(32 * (size_t)n2),
-                 oCs = oUr + up(uright2 ? 4 * (size_t)n2 : 0), oCi = oCs + up(4 * (size_t)(kCells + 1)),
-                 oHd = oCi + up(4 * (size_t)std::max(nItems, 1)),       // results: cursor, counts, offsets
-                 oCd = oHd + up(4 * (1 + 2 * (size_t)n1)), total = oCd + up(4 * (size_t)capTotal);
-    int rc = matcher_scratch(m, total, s);
+    const size_t oD1 = 0, oK2 = oD1 + up256z(32 * (size_t)n1), oD2 = oK2 + up256z(sizeof(orbx_keypoint) * n2),
+                 oUr = oD2 + up256z(32 * (size_t)n2), oCs = oUr + up256z(uright2 ? 4 * (size_t)n2 : 0),
+                 oCi = oCs + up256z(4 * (size_t)(kCells + 1)), oEnd = oCi + up256z(4 * (size_t)std::max(nItems, 1));
+    const WindowCoreLayout lay(n1, capTotal, oEnd, oEnd);
+    int rc = matcher_scratch(m, lay.scratchBytes, s);
     if (rc) return rc;
-    if ((rc = matcher_pinned(m, oCd))) return rc;
+    if ((rc = matcher_pinned(m, lay.pinBytes))) return rc;
     uint8_t* base = static_cast<uint8_t*>(m->scratch);
-    std::memcpy(m->pin + oQ, queries.data(), sizeof(WindowQuery) * n1);
     std::memcpy(m->pin + oD1, desc1, 32 * (size_t)n1);
     std::memcpy(m->pin + oK2, keys2, sizeof(orbx_keypoint) * n2);
     std::memcpy(m->pin + oD2, desc2, 32 * (size_t)n2);
     if (uright2) std::memcpy(m->pin + oUr, uright2, 4 * (size_t)n2);
     std::memcpy(m->pin + oCs, cell_start2, 4 * (size_t)(kCells + 1));
     if (nItems > 0) std::memcpy(m->pin + oCi, cell_items2, 4 * (size_t)nItems);
-    HIP_TRY(hipMemcpyAsync(base, m->pin, oHd, hipMemcpyHostToDevice, s));
-    const float invW = static_cast<float>(ORBX_GRID_COLS) / (max_x - min_x);
-    const float invH = static_cast<float>(ORBX_GRID_ROWS) / (max_y - min_y);
-    int32_t* hd = reinterpret_cast<int32_t*>(base + oHd);
-    HIP_TRY(launch_window_candidates(n1, reinterpret_cast<const WindowQuery*>(base + oQ), base + oD1,
-                                     reinterpret_cast<const orbx_keypoint*>(base + oK2), base + oD2,
-                                     uright2 ? reinterpret_cast<const float*>(base + oUr) : nullptr,
-                                     reinterpret_cast<const int32_t*>(base + oCs),
-                                     reinterpret_cast<const int32_t*>(base + oCi), min_x, min_y, invW, invH, capTotal,
-                                     hd, hd + 1, hd + 1 + n1, reinterpret_cast<uint32_t*>(base + oCd), s));
-    HIP_TRY(hipMemcpyAsync(m->pin + oHd, base + oHd, 4 * (1 + 2 * (size_t)n1), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    // the header leaves the pinned buffer before the buffer may grow for the candidate list
-    head.resize(1 + 2 * (size_t)n1);
-    std::memcpy(head.data(), m->pin + oHd, 4 * head.size());
-    const size_t ncand = (size_t)std::min(std::max(head[0], 0), capTotal);
-    if ((rc = matcher_pinned(m, std::max<size_t>(4 * ncand, 4)))) return rc;
-    if (ncand > 0) {
-        HIP_TRY(hipMemcpyAsync(m->pin, base + oCd, 4 * ncand, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpyAsync(base, m->pin, oEnd, hipMemcpyHostToDevice, s));
+    WindowDev in{base + oD1, reinterpret_cast<const orbx_keypoint*>(base + oK2), base + oD2,
+                 uright2 ? reinterpret_cast<const float*>(base + oUr) : nullptr,
+                 reinterpret_cast<const int32_t*>(base + oCs), reinterpret_cast<const int32_t*>(base + oCi)};
+    return window_search_core(m, who, queries, in, n2, min_x, min_y, max_x, max_y, lay, head, candHost);
+}
+
+// SearchForInitialization's queries: one per frame-1 keypoint of level 0 (src/ORBmatcher.cc:427-431), a window
+// around its previous match, level 0 only (:433).
+void initialization_queries(const orbx_keypoint* keys1_un, int n1, const float* prev_matched, int window_size,
+                            std::vector<WindowQuery>& queries) {
+    queries.resize(n1);
+    for (int i = 0; i < n1; i++) {
+        const int level1 = keys1_un[i].octave;
+        queries[i] = WindowQuery{prev_matched[2 * i], prev_matched[2 * i + 1], level1 > 0 ? -1.0f : (float)window_size,
+                                 0.0f, level1, level1};
     }
-    for (int i = 0; i < n1; i++)                      // a list must lie inside what was copied
-        if (head[1 + i] < 0 || head[1 + n1 + i] < 0 || (size_t)head[1 + n1 + i] + (size_t)head[1 + i] > ncand) {
-            set_error("%s: inconsistent candidate lists", who);
-            return ORBX_ERR_STATE;
-        }
-    return ORBX_OK;
 }
 }  // namespace
 
@@ -1233,19 +1361,56 @@ extern "C" int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoi
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     if (n1 == 0 || n2 == 0) return ORBX_OK;
     // one query per frame-1 keypoint of level 0 (:427-431): window around its previous match, level 0 only (:433)
-    std::vector<WindowQuery> queries(n1);
-    for (int i = 0; i < n1; i++) {
-        const int level1 = keys1_un[i].octave;
-        queries[i] = WindowQuery{prev_matched[2 * i], prev_matched[2 * i + 1], level1 > 0 ? -1.0f : (float)window_size,
-                                 0.0f, level1, level1};
-    }
+    std::vector<WindowQuery> queries;
+    initialization_queries(keys1_un, n1, prev_matched, window_size, queries);
     std::vector<int32_t> head;
+    const uint32_t* cand = nullptr;
     int rc = run_window_search(m, "orbx_search_for_initialization", queries, desc1, keys2_un, desc2, nullptr, n2,
-                               cell_start2, cell_items2, min_x, min_y, max_x, max_y, head);
+                               cell_start2, cell_items2, min_x, min_y, max_x, max_y, head, &cand);
     if (rc) return rc;
-    *nmatches = replay_search_for_initialization(keys1_un, n1, keys2_un, n2, head.data() + 1, head.data() + 1 + n1,
-                                                 reinterpret_cast<const uint32_t*>(m->pin), prev_matched, nnratio,
-                                                 check_orientation != 0, matches12);
+    *nmatches = replay_search_for_initialization(keys1_un, n1, keys2_un, n2, head.data(), head.data() + n1, cand,
+                                                 prev_matched, nnratio, check_orientation != 0, matches12);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_for_initialization_device(orbx_matcher* m, const orbx_keypoint* keys1_un,
+                                                     const uint8_t* d_desc1, int n1, const orbx_keypoint* keys2_un,
+                                                     const orbx_keypoint* d_keys2_un, const uint8_t* d_desc2, int n2,
+                                                     const int32_t* d_cell_start2, const int32_t* d_cell_items2,
+                                                     float min_x, float min_y, float max_x, float max_y,
+                                                     float* prev_matched, int window_size, float nnratio,
+                                                     int check_orientation, int32_t* matches12, int* nmatches) {
+    if (!m || n1 < 0 || n2 < 0 || !nmatches || !(max_x > min_x) || !(max_y > min_y) ||
+        (n1 > 0 && (!keys1_un || !d_desc1 || !prev_matched || !matches12)) ||
+        (n2 > 0 && (!keys2_un || !d_keys2_un || !d_desc2 || !d_cell_start2 || !d_cell_items2)) ||
+        ((uintptr_t)d_desc1 % 16) || ((uintptr_t)d_desc2 % 16)) {
+        set_error("orbx_search_for_initialization_device: bad argument (descriptor arrays must be 16-byte aligned)");
+        return ORBX_ERR_INVALID;
+    }
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    std::vector<WindowQuery> queries;
+    initialization_queries(keys1_un, n1, prev_matched, window_size, queries);
+    // the grid stays on the device, so the list is bounded by what any grid of n2 keypoints can hold
+    const long long capTotal = window_cap_total(queries, n2);
+    if (n2 > 0x7FFFFF || capTotal > 0x3FFFFFFF) {
+        set_error("orbx_search_for_initialization_device: too many keypoints (%d queries x %d)", n1, n2);
+        return ORBX_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    const WindowCoreLayout lay(n1, capTotal, 0, 0);
+    int rc = matcher_scratch(m, lay.scratchBytes, m->stream);
+    if (rc) return rc;
+    if ((rc = matcher_pinned(m, lay.pinBytes))) return rc;
+    const WindowDev in{d_desc1, d_keys2_un, d_desc2, nullptr, d_cell_start2, d_cell_items2};
+    std::vector<int32_t> head;
+    const uint32_t* cand = nullptr;
+    rc = window_search_core(m, "orbx_search_for_initialization_device", queries, in, n2, min_x, min_y, max_x, max_y,
+                            lay, head, &cand);
+    if (rc) return rc;
+    *nmatches = replay_search_for_initialization(keys1_un, n1, keys2_un, n2, head.data(), head.data() + n1, cand,
+                                                 prev_matched, nnratio, check_orientation != 0, matches12);
     return ORBX_OK;
 }
 
@@ -1287,11 +1452,11 @@ extern "C" int orbx_search_by_projection_frame(orbx_matcher* m, const float* pro
         queries[i] = q;
     }
     std::vector<int32_t> head;
+    const uint32_t* cand = nullptr;
     int rc = run_window_search(m, "orbx_search_by_projection_frame", queries, desc_mp, keys_un, desc, u_right, n,
-                               cell_start, cell_items, min_x, min_y, max_x, max_y, head);
+                               cell_start, cell_items, min_x, min_y, max_x, max_y, head, &cand);
     if (rc) return rc;
-    *nmatches = replay_search_by_projection_frame(npts, head.data() + 1, head.data() + 1 + npts,
-                                                  reinterpret_cast<const uint32_t*>(m->pin), last_angle,
+    *nmatches = replay_search_by_projection_frame(npts, head.data(), head.data() + npts, cand, last_angle,
                                                   has_observations, keys_un, occupied, n, max_dist,
                                                   check_orientation != 0, matches);
     return ORBX_OK;
@@ -1335,11 +1500,11 @@ extern "C" int orbx_search_by_projection_points(orbx_matcher* m, const float* pr
         queries[i] = q;
     }
     std::vector<int32_t> head;
+    const uint32_t* cand = nullptr;
     int rc = run_window_search(m, "orbx_search_by_projection_points", queries, desc_mp, keys_un, desc, u_right, n,
-                               cell_start, cell_items, min_x, min_y, max_x, max_y, head);
+                               cell_start, cell_items, min_x, min_y, max_x, max_y, head, &cand);
     if (rc) return rc;
-    *nmatches = replay_search_by_projection_points(npts, head.data() + 1, head.data() + 1 + npts,
-                                                   reinterpret_cast<const uint32_t*>(m->pin), has_observations,
+    *nmatches = replay_search_by_projection_points(npts, head.data(), head.data() + npts, cand, has_observations,
                                                    keys_un, occupied, n, nnratio, matches);
     return ORBX_OK;
 }

@@ -196,7 +196,7 @@ struct WindowQuery {
 hipError_t launch_window_candidates(int n1, const WindowQuery* queries, const uint8_t* d1, const orbx_keypoint* k2,
                                     const uint8_t* d2, const float* uRight2, const int32_t* cellStart,
                                     const int32_t* cellItems, float minX, float minY, float invW, float invH,
-                                    int capTotal, int32_t* cursor, int32_t* candCount, int32_t* candOffset,
+                                    int n2, int capTotal, int32_t* cursor, int32_t* candCount, int32_t* candOffset,
                                     uint32_t* cand, hipStream_t s);
 int replay_search_by_projection_frame(int npts, const int32_t* candCount, const int32_t* candOffset,
                                       const uint32_t* cand, const float* lastAngle, const uint8_t* hasObs,

@@ -21,7 +21,10 @@ struct GridParams {
 
 // A candidate is one word: distance << 23 | index in frame 2. A query's candidates are contiguous at
 // cand[candOffset[i1] ..) in visiting order; the regions are handed out by an atomic cursor after a counting pass,
-// so the list is as long as the candidates that exist and not n1 x (largest possible list).
+// so the list is as long as the candidates that exist and not n1 x (largest possible list). A query whose list
+// does not fit below capTotal reports the count -1. queries, candCount, candOffset and cand may be pinned host
+// memory (the kernel then reads its few inputs and leaves its results where the host replay picks them up, with
+// no copy in between); the cursor must be device memory.
 //
 // One wave per frame-1 keypoint. The window's cells, numbered in the reference's visiting order (columns outside,
 // rows inside, :387-410), are taken 64 at a time, one cell per lane, so the dependent loads of a cell (its start,
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const Wi
                                                                 const float* __restrict__ uRight2,
                                                                 const int32_t* __restrict__ cellStart,
                                                                 const int32_t* __restrict__ cellItems, GridParams gp,
-                                                                int capTotal, int32_t* __restrict__ cursor,
+                                                                int n2, int capTotal, int32_t* __restrict__ cursor,
                                                                 int32_t* __restrict__ candCount,
                                                                 int32_t* __restrict__ candOffset,
                                                                 uint32_t* __restrict__ cand) {
@@ -59,11 +62,13 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const Wi
                 jb = je = 0;
                 if (w < ncells) {
                     const int cx = w / rows, c = (nMinCellX + cx) * ORBX_GRID_ROWS + nMinCellY + (w - cx * rows);
-                    jb = cellStart[c];
-                    je = cellStart[c + 1];
+                    // a grid lists a keypoint at most once: whatever the arrays hold, the walk stays inside them
+                    jb = max(cellStart[c], 0);
+                    je = min(cellStart[c + 1], n2);
                 }
             };
             auto passes = [&](int i2) {
+                if ((unsigned)i2 >= (unsigned)n2) return false;
                 const orbx_keypoint kp = k2[i2];
                 // (src/Frame.cc:399-406; with bCheckLevels false both limits are below every octave)
                 if (kp.octave < q.minLevel || (q.maxLevel >= 0 && kp.octave > q.maxLevel)) return false;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const Wi
             if (total > 0) {
                 if (lane == 0) offset = atomicAdd(cursor, total);
                 offset = __builtin_amdgcn_readfirstlane(offset);
-                if (offset + total <= capTotal) {          // always true for a grid that lists a keypoint once
+                if (offset + total <= capTotal) {
                     const uint4 qa = d1[2 * i1], qb = d1[2 * i1 + 1];
                     int done = offset;
                     for (int chunk = 0; chunk < ncells; chunk += 64) {
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256) void window_candidates_kernel(int n1, const Wi
                         done += __builtin_amdgcn_readlane(incl, 63);
                     }
                 } else {
-                    total = 0;
+                    total = -1;                            // no room left in the list: the caller runs again with more
                 }
             }
         }
@@ -221,7 +226,7 @@ int replay_search_for_initialization(const orbx_keypoint* k1, int n1, const orbx
 hipError_t launch_window_candidates(int n1, const WindowQuery* queries, const uint8_t* d1, const orbx_keypoint* k2,
                                     const uint8_t* d2, const float* uRight2, const int32_t* cellStart,
                                     const int32_t* cellItems, float minX, float minY, float invW, float invH,
-                                    int capTotal, int32_t* cursor, int32_t* candCount, int32_t* candOffset,
+                                    int n2, int capTotal, int32_t* cursor, int32_t* candCount, int32_t* candOffset,
                                     uint32_t* cand, hipStream_t s) {
     if (n1 <= 0) return hipSuccess;
     GridParams gp{minX, minY, invW, invH};
@@ -229,7 +234,7 @@ hipError_t launch_window_candidates(int n1, const WindowQuery* queries, const ui
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(window_candidates_kernel, dim3((n1 + 3) / 4), dim3(256), 0, s, n1, queries,
                        reinterpret_cast<const uint4*>(d1), k2, reinterpret_cast<const uint4*>(d2), uRight2, cellStart,
-                       cellItems, gp, capTotal, cursor, candCount, candOffset, cand);
+                       cellItems, gp, n2, capTotal, cursor, candCount, candOffset, cand);
     return hipGetLastError();
 }
 

@@ -179,6 +179,31 @@ class HammingMatcher:
             "orbx_search_for_initialization")
         return n.value, out
 
+    def search_for_initialization_device(self, keys1_un, d_desc1, keys2_un, d_keys2_un, d_desc2, d_cell_start2,
+                                         d_cell_items2, bounds, prev_matched, window_size=100, nnratio=0.9,
+                                         check_orientation=True):
+        """search_for_initialization for two frames whose descriptors, undistorted keypoints and grid are still on
+        the GPU (torch CUDA tensors: d_desc1 (n1, 32) uint8, d_keys2_un (n2, 7) 28-byte records, d_desc2 (n2, 32),
+        d_cell_start2 (3073,) int32, d_cell_items2 (>= n2,) int32: one frame's slices of what extract_batch_device
+        and undistort_assign_grid_device wrote). keys1_un / keys2_un are the host copies of mvKeysUn."""
+        from ._lib import KEYPOINT_DTYPE
+        k1 = np.ascontiguousarray(keys1_un, dtype=KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(keys2_un, dtype=KEYPOINT_DTYPE)
+        assert prev_matched.dtype == np.float32 and prev_matched.flags.c_contiguous and prev_matched.shape == (len(k1), 2)
+        assert d_desc1.shape[0] >= len(k1) and d_desc2.shape[0] >= len(k2) and d_keys2_un.shape[0] >= len(k2)
+        for t in (d_desc1, d_keys2_un, d_desc2, d_cell_start2, d_cell_items2):
+            assert t.is_cuda and t.is_contiguous()
+        out = np.empty(len(k1), dtype=np.int32)
+        n = C.c_int(0)
+        self._before(None)
+        check(lib().orbx_search_for_initialization_device(
+            self._m, np_ptr(k1), C.c_void_p(d_desc1.data_ptr()), len(k1), np_ptr(k2), C.c_void_p(d_keys2_un.data_ptr()),
+            C.c_void_p(d_desc2.data_ptr()), len(k2), C.c_void_p(d_cell_start2.data_ptr()),
+            C.c_void_p(d_cell_items2.data_ptr()), float(bounds[0]), float(bounds[1]), float(bounds[2]),
+            float(bounds[3]), np_ptr(prev_matched), int(window_size), float(nnratio), 1 if check_orientation else 0,
+            np_ptr(out), C.byref(n)), "orbx_search_for_initialization_device")
+        return n.value, out
+
     def search_by_projection_frame(self, proj_uv, inv_z, last_octave, last_angle, desc_mp, has_observations,
                                    keys_un, desc, cell_start, cell_items, bounds, scale_factors, th, mbf=0.0,
                                    direction=0, u_right=None, occupied=None, check_orientation=True, max_dist=100):
@@ -275,6 +300,32 @@ class HammingMatcher:
             len(a[0]), np_ptr(k2), np_ptr(d2), None if v2 is None else np_ptr(v2), len(k2), np_ptr(b[0]),
             np_ptr(b[1]), np_ptr(b[2]), len(b[0]), float(nnratio), 1 if check_orientation else 0, np_ptr(out),
             C.byref(n)), "orbx_search_by_bow")
+        return n.value, out
+
+    def search_by_bow_device(self, keys1_un, d_desc1, valid1, fv1, keys2, d_desc2, fv2, valid2=None, nnratio=0.7,
+                             check_orientation=True, prepared=None):
+        """search_by_bow with the two descriptor arrays on the GPU (torch CUDA uint8 tensors (n, 32), e.g. one
+        frame's slice of what extract_batch_device wrote); everything else as in search_by_bow."""
+        from ._lib import KEYPOINT_DTYPE
+        k1 = np.ascontiguousarray(keys1_un, dtype=KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(keys2, dtype=KEYPOINT_DTYPE)
+        v1 = np.ascontiguousarray(valid1, dtype=np.uint8)
+        v2 = None if valid2 is None else np.ascontiguousarray(valid2, dtype=np.uint8)
+        a = [np.ascontiguousarray(fv1[0], dtype=np.uint32), np.ascontiguousarray(fv1[1], dtype=np.int32),
+             np.ascontiguousarray(fv1[2], dtype=np.uint32)]
+        b = [np.ascontiguousarray(fv2[0], dtype=np.uint32), np.ascontiguousarray(fv2[1], dtype=np.int32),
+             np.ascontiguousarray(fv2[2], dtype=np.uint32)]
+        assert d_desc1.is_cuda and d_desc2.is_cuda and d_desc1.is_contiguous() and d_desc2.is_contiguous()
+        assert d_desc1.shape[0] >= len(k1) and d_desc2.shape[0] >= len(k2)
+        mode = 0 if v2 is None else 1
+        out = np.empty(len(k2) if mode == 0 else len(k1), dtype=np.int32)
+        n = C.c_int(0)
+        self._before(None)
+        check(lib().orbx_search_by_bow_device(
+            self._m, mode, np_ptr(k1), C.c_void_p(d_desc1.data_ptr()), np_ptr(v1), len(k1), np_ptr(a[0]), np_ptr(a[1]),
+            np_ptr(a[2]), len(a[0]), np_ptr(k2), C.c_void_p(d_desc2.data_ptr()), None if v2 is None else np_ptr(v2),
+            len(k2), np_ptr(b[0]), np_ptr(b[1]), np_ptr(b[2]), len(b[0]), float(nnratio),
+            1 if check_orientation else 0, np_ptr(out), C.byref(n)), "orbx_search_by_bow_device")
         return n.value, out
 
     @staticmethod

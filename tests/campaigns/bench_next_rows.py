@@ -120,9 +120,33 @@ def main():
     n_gpu, _ = hm.search_for_initialization(k1, d1, k2, d2, start, items, b0, prev.copy())
     t_gpu = best_of(lambda: hm.search_for_initialization(k1, d1, k2, d2, start, items, b0, prev.copy()), 5, 4)
     t_cpu = best_of(lambda: orc.search_for_initialization(k1, d1, k2, d2, b0, prev.copy(), 100, 0.9, True), 3)
+    # the same search on device-resident frames: descriptors, mvKeysUn and the grid stay in HBM
+    import ctypes as C
+    from my_orb_slam2_amd._lib import lib, np_ptr
+    t_d1, t_d2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
+    t_k2 = torch.from_numpy(k2.view(np.uint8).reshape(-1, 28).copy()).cuda()
+    t_start, t_items = torch.from_numpy(start).cuda(), torch.from_numpy(np.ascontiguousarray(items, np.int32)).cuda()
+    torch.cuda.synchronize()
+    out12 = np.empty(len(k1), np.int32)
+    nm = C.c_int(0)
+    pv = prev.copy()
+
+    def init_dev():
+        pv[:] = prev
+        rc = lib().orbx_search_for_initialization_device(
+            hm._m, np_ptr(k1), C.c_void_p(t_d1.data_ptr()), len(k1), np_ptr(k2), C.c_void_p(t_k2.data_ptr()),
+            C.c_void_p(t_d2.data_ptr()), len(k2), C.c_void_p(t_start.data_ptr()), C.c_void_p(t_items.data_ptr()),
+            0.0, 0.0, 752.0, 480.0, np_ptr(pv), 100, 0.9, 1, np_ptr(out12), C.byref(nm))
+        assert rc == 0
+    init_dev()
+    assert nm.value == n_gpu
+    t_dev = best_of(init_dev, 7, 8)
     print(json.dumps({"step": "SearchForInitialization", "n1": len(k1), "n2": len(k2), "matches": int(n_gpu),
-                      "gpu_path_ms": round(t_gpu * 1e3, 3), "cpu_port_ms": round(t_cpu * 1e3, 3), "cpu_cores": 1,
-                      "note": "host arrays in and out; includes the copies and the host-side greedy pass"}))
+                      "gpu_path_ms": round(t_gpu * 1e3, 3), "gpu_device_resident_ms": round(t_dev * 1e3, 3),
+                      "cpu_port_ms": round(t_cpu * 1e3, 3), "cpu_cores": 1,
+                      "note": "gpu_path: host arrays in and out through the Python binding; gpu_device_resident: "
+                              "orbx_search_for_initialization_device called through the C ABI on data left in HBM; "
+                              "both include the host-side greedy pass"}))
 
     # ---- SearchByProjection(CurrentFrame, LastFrame) ----
     from tests.test_gpu_search_projection import make_case as proj_case, BOUNDS
@@ -144,10 +168,36 @@ def main():
             n_gpu, _ = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, **kw)
             t_gpu = best_of(lambda: hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, **kw), 5, 8)
             t_cpu = best_of(lambda: orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, **kw), 3, 2)
+            # both forms through the C ABI with arguments made once (the Python binding's own conversions cost
+            # tens of microseconds, comparable to the call)
+            t_d1, t_d2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
+            torch.cuda.synchronize()
+            a = [np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32),
+                 np.ascontiguousarray(fv1[2], np.uint32)]
+            bb = [np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32),
+                  np.ascontiguousarray(fv2[2], np.uint32)]
+            mode = 1 if kw else 0
+            outm = np.empty(len(k1) if mode else len(k2), np.int32)
+            nmb = C.c_int(0)
+            v2p = np_ptr(v2) if kw else None
+
+            def bow_c(fn, p1, p2):
+                rc = fn(hm._m, mode, np_ptr(k1), p1, np_ptr(v1), len(k1), np_ptr(a[0]), np_ptr(a[1]), np_ptr(a[2]),
+                        len(a[0]), np_ptr(k2), p2, v2p, len(k2), np_ptr(bb[0]), np_ptr(bb[1]), np_ptr(bb[2]), len(bb[0]),
+                        0.7, 1, np_ptr(outm), C.byref(nmb))
+                assert rc == 0 and nmb.value == n_gpu
+            host = lambda: bow_c(lib().orbx_search_by_bow, np_ptr(d1), np_ptr(d2))
+            dev = lambda: bow_c(lib().orbx_search_by_bow_device, C.c_void_p(t_d1.data_ptr()), C.c_void_p(t_d2.data_ptr()))
+            host(); dev()
+            t_host_c = best_of(host, 7, 16)
+            t_dev_c = best_of(dev, 7, 16)
             print(json.dumps({"step": name, "n1": len(k1), "n2": len(k2), "nodes": len(fv1[0]), "matches": int(n_gpu),
-                              "gpu_path_ms": round(t_gpu * 1e3, 3), "cpu_port_ms": round(t_cpu * 1e3, 3),
+                              "gpu_path_ms": round(t_gpu * 1e3, 3), "gpu_host_arrays_c_abi_ms": round(t_host_c * 1e3, 4),
+                              "gpu_device_resident_ms": round(t_dev_c * 1e3, 4), "cpu_port_ms": round(t_cpu * 1e3, 3),
                               "cpu_cores": 1,
-                              "note": "host arrays in and out; includes the copies and the host-side greedy pass"}))
+                              "note": "gpu_path: host arrays through the Python binding; *_c_abi / device_resident: the "
+                                      "C entry points called with ready-made arguments; all include the host-side "
+                                      "greedy pass"}))
 
 if __name__ == "__main__":
     main()

@@ -111,3 +111,64 @@ def test_search_for_initialization_refuses_a_malformed_grid():
     for s, it in ((start, bad_items), (start, bad_dup), (bad_start, items)):
         with pytest.raises(m.OrbxError):
             hm.search_for_initialization(k1, d1, k2, d2, s, it, bounds, prev.copy())
+
+
+def test_search_for_initialization_on_device_resident_frames():
+    """The whole chain without the frames' data leaving the GPU: batched extraction of both views, undistort +
+    grid on the device, then orbx_search_for_initialization_device on the descriptor / keypoint / grid slices of
+    the two frames; only the host copies of mvKeysUn (which a Frame holds anyway) go in from the host side.
+    Compared with the oracle and with the host-array form."""
+    import torch
+    cam = m.Camera(**dict(EUROC, k1=0.0, k2=0.0, p1=0.0, p2=0.0))
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    ex = m.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=2)
+    hm = m.HammingMatcher()
+    cap = ex.capacity
+    for idx, check_ori, window in ((83, True, 100), (84, False, 100), (85, True, 400)):
+        frames = np.stack([m.synth_frame(idx), m.synth_frame(idx, right_view=True)])
+        d_kps = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda")
+        d_desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(torch.from_numpy(frames).cuda(), d_kps, d_desc, d_cnt)
+        ex.synchronize()
+        d_un = torch.zeros_like(d_kps)
+        d_start = torch.zeros((2, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+        d_items = torch.full((2, cap), -1, dtype=torch.int32, device="cuda")
+        hm.undistort_assign_grid_device(d_kps, d_cnt, cam, bounds, d_un, d_start, d_items)
+        hm.synchronize()
+        cnt = d_cnt.cpu().numpy()
+        un = d_un.cpu().numpy().view(np.uint8).reshape(2, cap, 28).copy().view(m.KEYPOINT_DTYPE).reshape(2, cap)
+        k1, k2 = un[0, :cnt[0]].copy(), un[1, :cnt[1]].copy()
+        desc = d_desc.cpu().numpy()
+        d1, d2 = desc[0, :cnt[0]].copy(), desc[1, :cnt[1]].copy()
+        prev0 = np.stack([k1["x"], k1["y"]], 1).astype(np.float32).copy()
+        want_prev = prev0.copy()
+        want_n, want, want_prev = orc.search_for_initialization(k1, d1, k2, d2, bounds, want_prev, window, 0.9, check_ori)
+        prev = prev0.copy()
+        n, got = hm.search_for_initialization_device(k1, d_desc[0], k2, d_un[1], d_desc[1], d_start[1], d_items[1],
+                                                     bounds, prev, window, 0.9, check_ori)
+        assert n == want_n and np.array_equal(got, want) and np.array_equal(prev, want_prev)
+        assert n > 20
+        start, items = d_start[1].cpu().numpy(), d_items[1].cpu().numpy()[:cnt[1]]
+        prev = prev0.copy()
+        n2_, got2 = hm.search_for_initialization(k1, d1, k2, d2, start, items, bounds, prev, window, 0.9, check_ori)
+        assert n2_ == want_n and np.array_equal(got2, want) and np.array_equal(prev, want_prev)
+
+
+def test_candidate_lists_longer_than_the_pinned_budget():
+    """A window that covers the whole image makes every level-0 keypoint of frame 2 a candidate of every level-0
+    query: the packed lists outgrow what comes back in the first round trip and the second path (device list +
+    copy) must give the same answer."""
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    ex = m.ORBextractor(5000, 1.2, 8, 20, 7)
+    hm = m.HammingMatcher()
+    k1, d1 = ex(m.synth_frame(86))
+    k2, d2 = ex(m.synth_frame(86, right_view=True))
+    n0 = int((k1["octave"] == 0).sum())
+    assert n0 * int((k2["octave"] == 0).sum()) > max(1 << 16, 64 * len(k1))      # really beyond the budget
+    start, items = orc.assign_grid(k2, bounds)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32).copy()
+    want_prev = prev.copy()
+    want_n, want, want_prev = orc.search_for_initialization(k1, d1, k2, d2, bounds, want_prev, 2000, 0.9, True)
+    n, got = hm.search_for_initialization(k1, d1, k2, d2, start, items, bounds, prev, 2000, 0.9, True)
+    assert n == want_n and np.array_equal(got, want) and np.array_equal(prev, want_prev)

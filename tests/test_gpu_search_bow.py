@@ -55,19 +55,21 @@ def make_case(seed, n1, n2, n_nodes, noise_bits=20):
 @pytest.mark.parametrize("seed,n1,n2,n_nodes", [(1, 1000, 1200, 120), (2, 2000, 2000, 40), (3, 300, 50, 500),
                                                  (4, 1500, 1500, 3)])
 def test_search_by_bow_both_overloads(seed, n1, n2, n_nodes):
+    """Host-array form and the form with the descriptors resident on the GPU, both against the oracle."""
+    import torch
     k1, d1, v1, fv1, k2, d2, v2, fv2 = make_case(seed, n1, n2, n_nodes)
     hm = m.HammingMatcher(0)
+    t1, t2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
     total = 0
     for check_ori in (True, False):
         for ratio in (0.7, 0.9):
-            want_n, want = orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, None, ratio, check_ori)
-            n, got = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, None, ratio, check_ori)
-            assert n == want_n and np.array_equal(got, want)
-            total += n
-            want_n, want = orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, v2, ratio, check_ori)
-            n, got = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, v2, ratio, check_ori)
-            assert n == want_n and np.array_equal(got, want)
-            total += n
+            for valid2 in (None, v2):
+                want_n, want = orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, valid2, ratio, check_ori)
+                n, got = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, valid2, ratio, check_ori)
+                assert n == want_n and np.array_equal(got, want)
+                n, got = hm.search_by_bow_device(k1, t1, v1, fv1, k2, t2, fv2, valid2, ratio, check_ori)
+                assert n == want_n and np.array_equal(got, want)
+                total += n
     assert total > 0            # the case is not vacuous
 
 
@@ -95,3 +97,12 @@ def test_search_by_bow_edges():
     bad_start[2] = bad_start[1] - 1 if bad_start[1] > 0 else -1
     with pytest.raises(m.OrbxError):
         hm.search_by_bow(k1, d1, v1, fv1, k2, d2, (fv2[0], bad_start, fv2[2]))
+    # the device-resident form checks the same host arrays before anything runs
+    import torch
+    t1, t2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
+    n, got = hm.search_by_bow_device(k1, t1, v1, fv1, k2, t2, empty)
+    assert n == 0 and (got == -1).all() and len(got) == len(k2)
+    with pytest.raises(m.OrbxError):
+        hm.search_by_bow_device(k1, t1, v1, fv1, k2, t2, bad)
+    with pytest.raises(m.OrbxError):
+        hm.search_by_bow_device(k1, t1, v1, fv1, k2, t2, (fv2[0], bad_start, fv2[2]))
