@@ -63,6 +63,32 @@ __device__ __forceinline__ int corner_strength(const uint8_t* p) {
     return max(v - hiMin, loMax - v);      // darker-arc strength, brighter-arc strength
 }
 
+// Unsigned 16-bit operations on both halves of a dword.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+// Lanes whose low (word0) / high (word1) 16-bit half of a is below that of b, straight into a lane mask.
+__device__ __forceinline__ unsigned long long cmp_lt_word0(uint32_t a, uint32_t b) {
+    unsigned long long m;
+    asm("v_cmp_lt_u16_sdwa %0, %1, %2 src0_sel:WORD_0 src1_sel:WORD_0" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ unsigned long long cmp_lt_word1(uint32_t a, uint32_t b) {
+    unsigned long long m;
+    asm("v_cmp_lt_u16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_1" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+
 // number of set bits of m below this lane's own
 __device__ __forceinline__ int prefix_count(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -139,23 +165,29 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
         constexpr int kBatch = kTileRowBatch / kRowsPerStep;
         const int td = lane & (kRowLanes - 1), tr = lane / kRowLanes;
         uint32_t* tile32 = reinterpret_cast<uint32_t*>(tile) + tr * (PITCH / 4) + td;
-        // 32-bit offsets from the level's (wave-uniform) base. Rows past the tile re-read its last row, so no
-        // load leaves the level; they are stored too (the tile area holds whole batches of rows), which
-        // keeps every load and store unconditional.
-        const uint32_t col = (uint32_t)(xa + td * 4), stride32 = (uint32_t)rowStride;
+        // Rows come through a buffer resource over the level: a load's address is the scalar row offset plus this
+        // lane's constant offset, so a row of loads costs no vector instruction beyond the v_alignbyte (and a
+        // read past the level's last byte would return zero instead of faulting). Row groups past the tile's last
+        // one re-read that group (its rows may reach up to three rows below the cell, still inside the level:
+        // cells end 16 rows above the level's last row) and are stored too (the tile area holds whole batches
+        // of rows), which keeps every load and store unconditional.
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const int stride32 = (int)rowStride;                                  // a level is < 2^31 bytes
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, L.h * stride32, 0x00027000);
+        const int laneOff = (int)__umul24((uint32_t)tr, (uint32_t)stride32) + xa + td * 4;
+        const int lastGroup = ((th - 1) / kRowsPerStep) * kRowsPerStep;
         if (td < ndw) {
             for (int r0 = 0; r0 < th; r0 += kTileRowBatch) {
-                uint32_t lo[kBatch], hi[kBatch];
+                u32x2 v[kBatch];
 #pragma unroll
                 for (int q = 0; q < kBatch; q++) {
-                    const uint32_t row = (uint32_t)(iniY + min(r0 + tr + kRowsPerStep * q, th - 1));
-                    const uint8_t* src = img + (size_t)(__umul24(row, stride32) + col);
-                    lo[q] = reinterpret_cast<const uint32_t*>(src)[0];
-                    hi[q] = reinterpret_cast<const uint32_t*>(src)[1];
+                    const int row = iniY + min(r0 + kRowsPerStep * q, lastGroup);               // wave-uniform
+                    v[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, laneOff, row * stride32, 0);
                 }
 #pragma unroll
                 for (int q = 0; q < kBatch; q++)
-                    tile32[(r0 + kRowsPerStep * q) * (PITCH / 4)] = __builtin_amdgcn_alignbyte(hi[q], lo[q], shift);
+                    tile32[(r0 + kRowsPerStep * q) * (PITCH / 4)] = __builtin_amdgcn_alignbyte(v[q].y, v[q].x, shift);
             }
         }
     }
@@ -163,9 +195,10 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     uint16_t* queue = reinterpret_cast<uint16_t*>(score + g.maxScoreBytes);
     const int sp = sw + 2;
     {
-        uint32_t* s32 = reinterpret_cast<uint32_t*>(score);
-        const int ndw = (sp * (sh + 2) + 3) >> 2;
-        for (int i = lane; i < ndw; i += 64) s32[i] = 0;
+        // 16 bytes per lane and store; the last store may run a few bytes into the queue, which is filled later
+        uint4* s128 = reinterpret_cast<uint4*>(score);
+        const int n16 = (sp * (sh + 2) + 15) >> 4;
+        for (int i = lane; i < n16; i += 64) s128[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     wave_sync();
 
@@ -186,30 +219,52 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     int nq = 0;
     {
         constexpr int P4 = PITCH / 4;
-        unsigned long long xm[4];                      // lanes whose pixel j is inside the scan
+        // Thresholds as the packed test wants them, per 16-bit half: t << 8 to take from v << 8, (t << 8) | 0xFF to
+        // add to it. A pixel outside the scan (right of the cell's last column) gets 0xFFFF in both, which
+        // saturates its two limits to "nothing is darker" and "nothing is brighter": no mask needed later.
+        // Index 0: pixels 0 and 2 of the lane's group, index 1: pixels 1 and 3.
+        uint32_t tLo[2], tHi[2];
 #pragma unroll
-        for (int j = 0; j < 4; j++) xm[j] = __builtin_amdgcn_ballot_w64(4 * gx + j < sw);
+        for (int odd = 0; odd < 2; odd++) {
+            const uint32_t in0 = 4 * gx + odd < sw ? 0u : 0xFFFFu, in1 = 4 * gx + odd + 2 < sw ? 0u : 0xFFFF0000u;
+            tLo[odd] = ((uint32_t)tcur * 0x01000100u) | in0 | in1;
+            tHi[odd] = tLo[odd] | 0x00FF00FFu;
+        }
         int yx = (ly << 8) | (4 * gx);
         const int yxEnd = sh << 8;
         const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile) + (ly + 3) * P4 + gx;
         for (int y0 = 0; y0 < sh; y0 += rowsPerIter) {
             const uint32_t A = t32[0], B = t32[1], C = t32[2], U = t32[1 - 3 * P4], D = t32[1 + 3 * P4];
-            const unsigned long long ym = __builtin_amdgcn_ballot_w64(yx < yxEnd);
+            // Two pixels per instruction: a pixel rides in the high byte of a 16-bit half (an unsigned 16-bit
+            // min / max is decided by the high bytes, so whatever sits in the low bytes never reaches a result's
+            // high byte). Register E holds pixels 0 and 2 of the group, O pixels 1 and 3. Circle pixel k and
+            // its antipode k+8: a run of 9 holds at least one of each pair, so all pairs have a pixel < v-t
+            // <=> max over pairs of min < v-t; likewise for > v+t. Two of the eight pairs (0/8 above and below,
+            // 4/12 right and left) reject ~85% of the pixels; what passes goes on to the exact strength.
             unsigned long long m[4];
+            uint32_t mnmax[2], mxmin[2], lo[2], hi[2];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int v = (int)((B >> (8 * j)) & 0xff);
-                // circle pixel k and its antipode k+8: a run of 9 holds at least one of each pair
-                const int p8 = (int)((U >> (8 * j)) & 0xff), p0 = (int)((D >> (8 * j)) & 0xff);
-                const int p12 = (int)(((j < 3 ? A : B) >> (8 * ((j + 1) & 3))) & 0xff);
-                const int p4 = (int)(((j == 0 ? B : C) >> (8 * ((j + 3) & 3))) & 0xff);
-                // all pairs have a pixel < v-t  <=>  max over pairs of min < v-t; likewise for > v+t. Two of the
-                // eight pairs reject ~85% of the pixels; what passes goes straight to the exact strength.
-                const int mnmax = max(min(p0, p8), min(p4, p12));
-                const int mxmin = min(max(p0, p8), max(p4, p12));
-                // compare straight into lane masks (40 = signed <, 38 = signed >); the rest is scalar
-                m[j] = (__builtin_amdgcn_sicmp(mnmax, v - tcur, 40) | __builtin_amdgcn_sicmp(mxmin, v + tcur, 38)) &
-                       xm[j] & ym;
+            for (int odd = 0; odd < 2; odd++) {
+                const uint32_t vc = odd ? (B & 0xFF00FF00u) : __builtin_amdgcn_perm(B, B, 0x020c000cu);  // v << 8
+                const uint32_t p8 = odd ? U : U << 8, p0 = odd ? D : D << 8;
+                const uint32_t p12 = odd ? __builtin_amdgcn_perm(B, A, 0x040c020cu) : A;
+                const uint32_t p4 = odd ? C << 8 : __builtin_amdgcn_perm(C, B, 0x050c030cu);
+                mnmax[odd] = pk_max(pk_min(p0, p8), pk_min(p4, p12));
+                mxmin[odd] = pk_min(pk_max(p0, p8), pk_max(p4, p12));
+                // (v - t) << 8 with low byte 0x00 and (v + t) << 8 with low byte 0xFF, both saturating: the low
+                // bytes decide a comparison between equal high bytes the way the pixel comparison wants it
+                lo[odd] = pk_sub_sat(vc, tLo[odd]);
+                hi[odd] = pk_add_sat(vc, tHi[odd]);
+            }
+#pragma unroll
+            for (int odd = 0; odd < 2; odd++) {
+                m[odd] = cmp_lt_word0(mnmax[odd], lo[odd]) | cmp_lt_word0(hi[odd], mxmin[odd]);
+                m[odd + 2] = cmp_lt_word1(mnmax[odd], lo[odd]) | cmp_lt_word1(hi[odd], mxmin[odd]);
+            }
+            if (y0 + rowsPerIter > sh) {               // last step: lanes on rows below the scan drop out
+                const unsigned long long ym = __builtin_amdgcn_ballot_w64(yx < yxEnd);
+#pragma unroll
+                for (int j = 0; j < 4; j++) m[j] &= ym;
             }
             // row-major rank: everything queued by lower lanes, then this lane's own earlier pixels
             int pos = nq;
@@ -258,8 +313,9 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
             x = yx & 255;
             const uint8_t* s = score + (y + 1) * sp + x + 1;
             sc = s[0] - 1;                           // every queued pixel is a corner at this threshold
-            int nb = max(max(s[-1], s[1]), max(max(s[-sp - 1], s[-sp]), s[-sp + 1]));
-            nb = max(nb, max(max(s[sp - 1], s[sp]), s[sp + 1]));
+            const int a0 = s[-sp - 1], a1 = s[-sp], a2 = s[-sp + 1], a3 = s[-1], a4 = s[1], a5 = s[sp - 1], a6 = s[sp],
+                      a7 = s[sp + 1];
+            const int nb = max(max(max(a0, a1), max(a2, a3)), max(max(a4, a5), max(a6, a7)));
             // the map holds S only for corners (S > threshold); everything else counts as score 0
             keep = sc > max(nb - 1, 0);
         }
