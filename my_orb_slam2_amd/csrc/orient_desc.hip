@@ -11,8 +11,8 @@
 //   R  raw bytes, 44 rows x 48 B; LDS column j is image column kx - 23 + j for every keypoint (the
 //      dword loads are re-aligned with v_alignbyte on the way in), so all later indices are constants
 //   T  row sums as u16 (they never exceed 257*255), rows 2j and 2j+1 packed into one dword per column,
-//      22 x 44 dwords. One lane makes both rows of a pair for four columns (v_alignbyte +
-//      v_dot4_u32_u8) and stores them as one 16-byte write.
+//      22 x 44 dwords. One lane makes both rows of a pair for four columns (v_dot4_u32_u8 of the three dwords
+//      around the group with the tap vector shifted per column) and stores them as one 16-byte write.
 //   Bl blurred bytes, 38 x 44 (overlays R once the row pass is done). One lane makes blurred rows 2p
 //      and 2p+1 for four columns from the same four packed row pairs (v_dot2_u32_u16; the 7 taps
 //      straddle the pairs as (K0,K1)(K2,K3)(K4,K5)(K6,-) for the even row and (-,K0)(K1,K2)(K3,K4)(K5,K6)
@@ -231,8 +231,28 @@ __device__ __forceinline__ uint32_t pack4_sat(const uint4& v) {
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);   // low halves of lo and hi
 }
 
-__device__ __forceinline__ uint32_t row_sum4(uint32_t x, uint32_t klo, uint32_t khi, uint32_t y) {
-    return __builtin_amdgcn_udot4(x, klo, __builtin_amdgcn_udot4(y, khi, 0u, false), false);
+// The seven taps laid over the twelve bytes A B C (columns 4g-4 .. 4g+7) for the four output columns 4g+j: column
+// 4g+j takes bytes j+1 .. j+7, so its weights are the tap vector shifted by j+1 bytes and cut into three dwords.
+// The products go through v_dot4_u32_u8 with the weights as scalar operands: no realignment of the pixels.
+struct RowTaps {
+    uint32_t a0, b0;            // j = 0: bytes 1..7 (A: -,K0,K1,K2; B: K3..K6)
+    uint32_t a1, b1, c1;        // j = 1: bytes 2..8
+    uint32_t a2, b2, c2;        // j = 2: bytes 3..9
+    uint32_t b3, c3;            // j = 3: bytes 4..10 (B: K0..K3; C: K4,K5,K6,-)
+};
+__device__ __forceinline__ RowTaps make_row_taps(int blurTaps) {
+    const uint32_t k0 = 18, k1 = 34, k2 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 49 : 48,
+                   k3 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 55 : 56;
+    auto w = [](uint32_t x, uint32_t y, uint32_t z, uint32_t u) { return x | (y << 8) | (z << 16) | (u << 24); };
+    RowTaps t;
+    t.a0 = w(0, k0, k1, k2);  t.b0 = w(k3, k2, k1, k0);
+    t.a1 = w(0, 0, k0, k1);   t.b1 = w(k2, k3, k2, k1);  t.c1 = w(k0, 0, 0, 0);
+    t.a2 = w(0, 0, 0, k0);    t.b2 = w(k1, k2, k3, k2);  t.c2 = w(k1, k0, 0, 0);
+    t.b3 = w(k0, k1, k2, k3); t.c3 = w(k2, k1, k0, 0);
+    return t;
+}
+__device__ __forceinline__ uint32_t dot4(uint32_t x, uint32_t w, uint32_t acc) {
+    return __builtin_amdgcn_udot4(x, w, acc, false);
 }
 
 }  // namespace
@@ -312,21 +332,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
         const int colLo = min(max(xa + 4 * d, 0), rowStride - 4), colHi = min(max(xa + 4 * d + 4, 0), rowStride - 4);
         const bool rowsInside = ky - kPR >= 0 && ky - kPR + kRowsAlloc <= L.h;
         uint32_t lo[kRowsAlloc / 4], hi[kRowsAlloc / 4];
+        // Rows come through a buffer resource over the level: the row offset is scalar, the two dword offsets are
+        // this lane's constants, so a load needs no address arithmetic (and cannot fault).
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, L.h * rowStride, 0x00027000);
         if (rowsInside) {
-            const uint8_t* src = img + (long long)(ky - kPR + rs) * rowStride;
+            const int offLo = rs * rowStride + colLo, offHi = rs * rowStride + colHi;
+            const int row0 = (ky - kPR) * rowStride;                         // wave-uniform
 #pragma unroll
             for (int q = 0; q < kRowsAlloc / 4; q++) {
-                lo[q] = *reinterpret_cast<const uint32_t*>(src + colLo);
-                hi[q] = *reinterpret_cast<const uint32_t*>(src + colHi);
-                src += 4 * (long long)rowStride;
+                lo[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, offLo, row0 + 4 * q * rowStride, 0);
+                hi[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, offHi, row0 + 4 * q * rowStride, 0);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < kRowsAlloc / 4; q++) {
                 const int sy = reflect101(ky - kPR + rs + 4 * q, L.h);
-                const uint8_t* src = img + (long long)sy * rowStride;
-                lo[q] = *reinterpret_cast<const uint32_t*>(src + colLo);
-                hi[q] = *reinterpret_cast<const uint32_t*>(src + colHi);
+                lo[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, sy * rowStride + colLo, 0, 0);
+                hi[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, sy * rowStride + colHi, 0, 0);
             }
         }
         if (d < 12) {
@@ -366,8 +389,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // ---- row pass: T[r][j] = sum_c K[c] * R[r][j-3+c]; a lane makes rows 2j, 2j+1 of four columns ----
-    const uint32_t klo = blurTaps == ORBX_BLUR_CV_4_0_0 ? 0x37312212u : 0x38302212u;  // K0..K3
-    const uint32_t khi = blurTaps == ORBX_BLUR_CV_4_0_0 ? 0x00122231u : 0x00122230u;  // K4..K6
+    const RowTaps kt = make_row_taps(blurTaps);
 #pragma unroll
     for (int q = 0; q < kHIters; q++) {
         const uint32_t* p = reinterpret_cast<const uint32_t*>(R + (hItem[q] & 0xFFFFu));
@@ -375,13 +397,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t A = p[12 * h], B = p[12 * h + 1], C = p[12 * h + 2];   // columns 4g-4 .. 4g+7
-            o[h].x = row_sum4(__builtin_amdgcn_alignbyte(B, A, 1), klo, khi, __builtin_amdgcn_alignbyte(C, B, 1));
-            o[h].y = row_sum4(__builtin_amdgcn_alignbyte(B, A, 2), klo, khi, __builtin_amdgcn_alignbyte(C, B, 2));
-            o[h].z = row_sum4(__builtin_amdgcn_alignbyte(B, A, 3), klo, khi, __builtin_amdgcn_alignbyte(C, B, 3));
-            o[h].w = row_sum4(B, klo, khi, C);
+            o[h].x = dot4(A, kt.a0, dot4(B, kt.b0, 0u));
+            o[h].y = dot4(A, kt.a1, dot4(B, kt.b1, dot4(C, kt.c1, 0u)));
+            o[h].z = dot4(A, kt.a2, dot4(B, kt.b2, dot4(C, kt.c2, 0u)));
+            o[h].w = dot4(B, kt.b3, dot4(C, kt.c3, 0u));
         }
         *reinterpret_cast<uint4*>(Tb + (hItem[q] >> 16)) =
-            make_uint4(o[0].x | (o[1].x << 16), o[0].y | (o[1].y << 16), o[0].z | (o[1].z << 16), o[0].w | (o[1].w << 16));
+            make_uint4(__builtin_amdgcn_perm(o[1].x, o[0].x, 0x05040100u), __builtin_amdgcn_perm(o[1].y, o[0].y, 0x05040100u),
+                       __builtin_amdgcn_perm(o[1].z, o[0].z, 0x05040100u), __builtin_amdgcn_perm(o[1].w, o[0].w, 0x05040100u));
     }
     wave_sync();
 
