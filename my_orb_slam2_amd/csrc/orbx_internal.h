@@ -78,6 +78,39 @@ struct ResizeTab {
     int xmax;
 };
 
+// ---- several pyramid levels in one launch (pyramid.hip) ----
+// A group is a run of consecutive destination levels made by one kernel: a workgroup owns a tile of the group's
+// last level and works its way down to it from the group's source level, keeping the tiles of the levels in
+// between in LDS (each is also written to the pyramid buffer, every pixel by exactly one workgroup).
+constexpr int kFusedMaxLevels = 8;
+struct FusedRange {             // per (level of the group, tile column) or (level, tile row)
+    int lo, hi;                 // columns (rows) of the level this tile computes; columns in multiples of four
+    int ownLo, ownHi;           // the part of them it writes to the pyramid buffer
+};
+struct FusedLevel {
+    int dw, dh;                 // destination level
+    int sw, sh;                 // its source level
+    long long dstOffset;        // of the destination level inside a frame's pyramid buffer
+    int dstStride;
+    const int32_t* xentry;      // as ResizeTab
+    const int32_t* yofs;
+    const uint32_t* beta2;      // ibeta read as one dword per row
+};
+struct FusedGroup {
+    int nl, ntx, nty;
+    int bufBytes;               // bytes of each of the two LDS tile buffers
+    const uint8_t* src;         // the group's source level of frame 0
+    long long srcRowStride, srcFrameStride;
+    const FusedRange* cols;     // [nl][ntx]
+    const FusedRange* rows;     // [nl][nty]
+    FusedLevel lv[kFusedMaxLevels];
+};
+struct FusedPlan {
+    std::vector<FusedGroup> groups;         // cols / rows hold offsets into `ranges` until the plan is uploaded
+    std::vector<int> firstLevel;            // source level of each group
+    std::vector<FusedRange> ranges;         // all range tables, one after the other
+};
+
 // candidate packing: x (12 bits) | y (12 bits) << 12 | score << 24; x, y relative to the 16-px border
 __host__ __device__ inline uint32_t pack_cand(int x, int y, int score) {
     return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)score << 24);
@@ -127,7 +160,12 @@ hipError_t launch_repack_frames(const uint8_t* src, long long srcRowStride, long
                                 long long dstRowStride, long long dstFrameStride, int w, int h, int nframes,
                                 hipStream_t s);
 hipError_t launch_pyramid(const FrameSet& fs, const PyramidGeom& g, const ResizeTab* tabs, int nframes,
-                          hipStream_t s);
+                          hipStream_t s, const FusedPlan* fused = nullptr);
+struct HostResizeTab;
+// Plans the grouped launches for a geometry (tileW x tileH = tile of a group's last level). Leaves the plan empty
+// when a level does not qualify (step between levels above 2, tiles wider than the kernel's lanes).
+void plan_fused_pyramid(const PyramidGeom& g, const std::vector<HostResizeTab>& ht, const ResizeTab* devTabs,
+                        int tileW, int tileH, int groupLevels, FusedPlan& plan);
 hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nframes, int iniTh, int minTh,
                              hipStream_t s);
 hipError_t launch_octree(const FrameSet& fs, const PyramidGeom& g, int nframes, hipStream_t s);

@@ -160,8 +160,233 @@ hipError_t launch_repack_frames(const uint8_t* src, long long srcRowStride, long
     return hipGetLastError();
 }
 
+// ---- several levels per launch ----
+// The arithmetic of one strip of destination rows for four adjacent columns, exactly as in
+// pyr_resize_dword_kernel; only where a source row comes from differs: FROM_LDS = false reads the group's source
+// level through a buffer resource, true reads the tile of the level above that this workgroup has just made.
+template <bool FROM_LDS, typename Store>
+__device__ __forceinline__ void resize_strip(const FusedLevel& Lv, int x4, int dyBegin, int dyEnd,
+                                             __amdgpu_buffer_rsrc_t rsrc, int srcRowStride, const uint32_t* in32,
+                                             int inPitch4, int inC0, int inR0, Store store) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const uint4* xe = reinterpret_cast<const uint4*>(Lv.xentry + 2 * x4);
+    const uint4 e01 = xe[0], e23 = xe[1];
+    const int sx0 = (int)e01.x;
+    const uint32_t sel[4] = {0x0c010c00u, e01.z, e23.x, e23.z};
+    const uint32_t aa[4] = {e01.y, e01.w, e23.y, e23.w};
+    const uint32_t sh8 = (uint32_t)(sx0 & 3);
+    const int q0 = sx0 >> 2;
+    const int lastDw = ((Lv.sw + 3) >> 2) - 1;
+    const int o0 = 4 * min(q0, lastDw), o1 = 4 * min(q0 + 1, lastDw), o2 = 4 * min(q0 + 2, lastDw);
+    const int qrel = q0 - (inC0 >> 2);
+    auto hrow = [&](int sy, uint32_t (&h)[4]) {
+        uint32_t u0, u1, u2;
+        if (FROM_LDS) {
+            const uint32_t* r = in32 + (sy - inR0) * inPitch4 + qrel;
+            u0 = r[0]; u1 = r[1]; u2 = r[2];
+        } else {
+            const int rowOff = sy * srcRowStride;
+            u0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, o0 + rowOff, 0, 0);
+            u1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, o1 + rowOff, 0, 0);
+            u2 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, o2 + rowOff, 0, 0);
+        }
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(u1, u0, sh8), w1 = __builtin_amdgcn_alignbyte(u2, u1, sh8);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(w1, w0, sel[k])),
+                                          __builtin_bit_cast(us2, aa[k]), 0u, false) >> 4;
+    };
+    int cachedSy = -1;
+    uint32_t hA[4] = {0, 0, 0, 0}, hB[4] = {0, 0, 0, 0};
+    auto row = [&](int dy, uint32_t (&up)[4], uint32_t (&lo)[4]) {
+        int sy0 = Lv.yofs[dy], sy1 = sy0 + 1;
+        sy0 = min(max(sy0, 0), Lv.sh - 1);
+        sy1 = min(max(sy1, 0), Lv.sh - 1);
+        const uint32_t bb = Lv.beta2[dy];
+        if (sy0 != cachedSy) hrow(sy0, up);
+        hrow(sy1, lo);
+        cachedSy = sy1;
+        const uint32_t b0 = bb << 16, b1 = bb & 0xFFFF0000u;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = __umulhi(b0, up[k]) + __umulhi(b1, lo[k]) + 2u;
+        const uint32_t p01 = (v[0] | (v[1] << 16)) >> 2, p23 = (v[2] | (v[3] << 16)) >> 2;
+        store(dy, __builtin_amdgcn_perm(p23, p01, 0x06040200u));
+    };
+    for (int dy = dyBegin; dy < dyEnd; dy += 2) {
+        row(dy, hA, hB);
+        if (dy + 1 < dyEnd) row(dy + 1, hB, hA);
+    }
+}
+
+__global__ __launch_bounds__(256) void pyr_fused_kernel(FusedGroup G, uint8_t* __restrict__ pyr, long long pyrBytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int f = blockIdx.x;                                  // frame-fastest grid: one frame per XCD
+    const int ty = blockIdx.y / G.ntx, tx = blockIdx.y - ty * G.ntx;
+    const int t = threadIdx.x;
+    uint8_t* frameDst = pyr + (long long)f * pyrBytes;
+    const uint8_t* src = G.src + (long long)f * G.srcFrameStride;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(src), 0, (int)((long long)G.lv[0].sh * G.srcRowStride), 0x00027000);
+    int inC0 = 0, inR0 = 0, inPitch4 = 0;
+    for (int j = 0; j < G.nl; j++) {
+        const FusedLevel& Lv = G.lv[j];
+        const FusedRange cr = G.cols[j * G.ntx + tx], rr = G.rows[j * G.nty + ty];
+        const int ncg = (cr.hi - cr.lo) >> 2, nr = rr.hi - rr.lo;
+        // a power-of-two number of lanes per row of column groups; the other lanes' bits pick the strip of rows
+        int lg = 0;
+        while ((1 << lg) < ncg) lg++;
+        const int cg = t & ((1 << lg) - 1), strip = t >> lg;
+        const int rps = (nr + (256 >> lg) - 1) >> (8 - lg);
+        const int dyBegin = rr.lo + strip * rps, dyEnd = min(dyBegin + rps, rr.hi);
+        const int outPitch4 = ncg + 2;                          // two spare dwords: the 12-byte window of the next level
+        uint32_t* out32 = reinterpret_cast<uint32_t*>(lds + (j & 1) * G.bufBytes);
+        const uint32_t* in32 = reinterpret_cast<const uint32_t*>(lds + ((j + 1) & 1) * G.bufBytes);
+        if (cg < ncg && dyBegin < dyEnd) {
+            const int x4 = cr.lo + 4 * cg;
+            const bool keep = j + 1 < G.nl, ownCol = x4 >= cr.ownLo && x4 < cr.ownHi;
+            uint8_t* dst = frameDst + Lv.dstOffset + x4;
+            auto store = [&](int dy, uint32_t px) {
+                if (keep) out32[(dy - rr.lo) * outPitch4 + cg] = px;
+                if (ownCol && dy >= rr.ownLo && dy < rr.ownHi)
+                    *reinterpret_cast<uint32_t*>(dst + (long long)dy * Lv.dstStride) = px;
+            };
+            if (j == 0)
+                resize_strip<false>(Lv, x4, dyBegin, dyEnd, rsrc, (int)G.srcRowStride, nullptr, 0, 0, 0, store);
+            else
+                resize_strip<true>(Lv, x4, dyBegin, dyEnd, rsrc, 0, in32, inPitch4, inC0, inR0, store);
+        }
+        inC0 = cr.lo;
+        inR0 = rr.lo;
+        inPitch4 = outPitch4;
+        __syncthreads();
+    }
+}
+
+namespace {
+// Ranges of one dimension of a group: tiles of `tile` units on the last level, and for every level above it what
+// each tile has to compute (the sources of what it computes one level down) and which part of that it owns.
+// ofs[j][i] = source index (in level j-1 of the group, or the group's source for j = 0) of index i of level j,
+// already clamped into the source. n[j] = size of level j. align = 4 for columns (dword granularity), 1 for rows.
+void plan_dimension(const std::vector<const int32_t*>& ofs, const std::vector<int>& n, const std::vector<int>& nsrc,
+                    int tile, int align, std::vector<std::vector<FusedRange>>& out) {
+    const int nl = (int)n.size();
+    auto up = [&](int v) { return (v + align - 1) / align * align; };
+    auto down = [&](int v) { return v / align * align; };
+    const int last = nl - 1;
+    const int nt = (n[last] + tile - 1) / tile;
+    out.assign(nl, std::vector<FusedRange>(nt));
+    for (int i = 0; i < nt; i++) {
+        const int lo = i * tile, hi = std::min((i + 1) * tile, up(n[last]));
+        out[last][i] = FusedRange{lo, i + 1 == nt ? up(n[last]) : hi, lo, i + 1 == nt ? up(n[last]) : hi};
+    }
+    for (int j = last - 1; j >= 0; j--) {
+        std::vector<int> start(nt + 1), needHi(nt);
+        for (int i = 0; i < nt; i++) {
+            const FusedRange& c = out[j + 1][i];
+            const int first = std::min(c.lo, n[j + 1] - 1), lastIdx = std::min(c.hi, n[j + 1]) - 1;
+            auto srcOf = [&](int idx) { return std::min(std::max(ofs[j + 1][idx], 0), nsrc[j + 1] - 1); };
+            start[i] = i == 0 ? 0 : down(srcOf(first));
+            needHi[i] = std::min(srcOf(lastIdx) + 1, nsrc[j + 1] - 1) + 1;
+        }
+        start[nt] = up(n[j]);
+        for (int i = 0; i < nt; i++) start[i] = std::min(start[i], start[nt]);
+        for (int i = nt - 1; i > 0; i--) start[i] = std::min(start[i], start[i + 1]);   // (already monotone; kept safe)
+        for (int i = 0; i < nt; i++) {
+            FusedRange r;
+            r.lo = r.ownLo = start[i];
+            r.ownHi = start[i + 1];
+            r.hi = std::min(std::max(up(needHi[i]), r.ownHi), up(n[j]));
+            r.hi = std::max(r.hi, r.lo);
+            out[j][i] = r;
+        }
+    }
+}
+}  // namespace
+
+void plan_fused_pyramid(const PyramidGeom& g, const std::vector<HostResizeTab>& ht, const ResizeTab* devTabs,
+                        int tileW, int tileH, int groupLevels, FusedPlan& plan) {
+    plan = FusedPlan();
+    const int nd = g.nlevels - 1;                      // derived levels 1 .. nlevels-1
+    if (nd < 1) return;
+    for (int l = 0; l < g.nlevels; l++)
+        if (g.lv[l].w < 1 || g.lv[l].h < 1) return;
+    for (int l = 1; l < g.nlevels; l++)
+        if (devTabs[l].maxSpan > 6) return;            // the 8-byte window of the fast path
+    FusedPlan p;
+    int first = 0;
+    while (first < nd) {
+        const int nl = std::min(std::min(groupLevels, kFusedMaxLevels), nd - first);
+        FusedGroup G{};
+        G.nl = nl;
+        std::vector<const int32_t*> xo(nl), yo(nl);
+        std::vector<int> nw(nl), nh(nl), sw(nl), sh(nl);
+        for (int j = 0; j < nl; j++) {
+            const int l = first + 1 + j;               // destination level
+            FusedLevel& F = G.lv[j];
+            F.dw = g.lv[l].w; F.dh = g.lv[l].h; F.sw = g.lv[l - 1].w; F.sh = g.lv[l - 1].h;
+            F.dstOffset = g.lv[l].offset; F.dstStride = g.lv[l].stride;
+            F.xentry = devTabs[l].xentry; F.yofs = devTabs[l].yofs;
+            F.beta2 = reinterpret_cast<const uint32_t*>(devTabs[l].ibeta);
+            xo[j] = ht[l].xofs.data(); yo[j] = ht[l].yofs.data();
+            nw[j] = F.dw; nh[j] = F.dh; sw[j] = F.sw; sh[j] = F.sh;
+        }
+        // the widest tile of the group must fit the 32 lanes a row of column groups gets: narrow the tiles until it does
+        std::vector<std::vector<FusedRange>> cols, rows;
+        plan_dimension(yo, nh, sh, tileH, 1, rows);
+        int tw = std::max(tileW & ~3, 8), buf = 0;
+        for (;; tw -= 8) {
+            if (tw < 8) return;
+            plan_dimension(xo, nw, sw, tw, 4, cols);
+            int widest = 0;
+            buf = 0;
+            for (int j = 0; j < nl; j++) {
+                int wmax = 0, hmax = 0;
+                for (const FusedRange& r : cols[j]) wmax = std::max(wmax, r.hi - r.lo);
+                for (const FusedRange& r : rows[j]) hmax = std::max(hmax, r.hi - r.lo);
+                widest = std::max(widest, wmax);
+                if (j + 1 < nl) buf = std::max(buf, (wmax + 8) * hmax);
+            }
+            if (widest <= 128) break;
+        }
+        G.ntx = (int)cols[0].size();
+        G.nty = (int)rows[0].size();
+        G.bufBytes = (buf + 15) & ~15;
+        if (2 * G.bufBytes > 64 * 1024) return;
+        G.cols = reinterpret_cast<const FusedRange*>(p.ranges.size());      // offsets until uploaded
+        for (int j = 0; j < nl; j++) p.ranges.insert(p.ranges.end(), cols[j].begin(), cols[j].end());
+        G.rows = reinterpret_cast<const FusedRange*>(p.ranges.size());
+        for (int j = 0; j < nl; j++) p.ranges.insert(p.ranges.end(), rows[j].begin(), rows[j].end());
+        p.groups.push_back(G);
+        p.firstLevel.push_back(first);
+        first += nl;
+    }
+    plan = p;
+}
+
 hipError_t launch_pyramid(const FrameSet& fs, const PyramidGeom& g, const ResizeTab* tabs, int nframes,
-                          hipStream_t s) {
+                          hipStream_t s, const FusedPlan* fused) {
+    const bool level0Aligned = ((uintptr_t)fs.img % 4 == 0) && (fs.imgRowStride % 4 == 0) && (fs.imgFrameStride % 4 == 0);
+    if (fused && !fused->groups.empty() && level0Aligned) {
+        for (size_t k = 0; k < fused->groups.size(); k++) {
+            FusedGroup G = fused->groups[k];
+            const int l0 = fused->firstLevel[k];
+            if (l0 == 0) {
+                G.src = fs.img;
+                G.srcRowStride = fs.imgRowStride;
+                G.srcFrameStride = fs.imgFrameStride;
+            } else {
+                G.src = fs.pyr + g.lv[l0].offset;
+                G.srcRowStride = g.lv[l0].stride;
+                G.srcFrameStride = g.pyrBytes;
+            }
+            hipLaunchKernelGGL(pyr_fused_kernel, dim3(nframes, G.ntx * G.nty, 1), dim3(256, 1, 1), 2 * (size_t)G.bufBytes, s,
+                               G, fs.pyr, g.pyrBytes);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     for (int l = 1; l < g.nlevels; l++) {
         const LevelGeom& D = g.lv[l];
         const LevelGeom& S = g.lv[l - 1];

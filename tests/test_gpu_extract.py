@@ -336,6 +336,29 @@ def test_api_errors_and_empty_image():
         m.ORBextractor(1000, 1.0, 8, 20, 7)
 
 
+def test_both_pyramid_kernels_against_the_oracle():
+    """Up to eight frames per call take the one-launch pyramid kernel (every level from LDS tiles), larger batches
+    the level-by-level kernel: every level of both must equal the oracle's, byte for byte, also for sizes whose
+    tiles end in partial dwords and for a pyramid with more levels than one tile chain holds."""
+    for w, h, nlevels, scale in ((752, 480, 8, 1.2), (641, 367, 8, 1.2), (333, 250, 12, 1.1), (500, 300, 4, 1.7)):
+        B = 12
+        gpu, cpu = make(nfeatures=600, w=w, h=h, batch=B, nlevels=nlevels, scale=scale)
+        frames = np.stack([m.synth_frame(700 + i, w, h) for i in range(B)])
+        big = gpu.extract_batch(frames)                       # level by level
+        levels_big = {i: [gpu.get_level(l, frame=i) for l in range(nlevels) if gpu.level_size(l)[0] > 0] for i in (0, B - 1)}
+        for i in (0, B - 1):
+            ck, cd = cpu.extract(frames[i])
+            want = [cpu.level_image(l) for l in range(nlevels) if cpu.level_size(l)[0] > 0]
+            assert len(want) == len(levels_big[i])
+            for l, (a, b) in enumerate(zip(levels_big[i], want)):
+                assert np.array_equal(a, b), "level-by-level kernel, %dx%d level %d" % (w, h, l)
+            small = gpu.extract_batch(frames[i:i + 1])        # one launch
+            for l, b in enumerate(want):
+                assert np.array_equal(gpu.get_level(l), b), "one-launch kernel, %dx%d level %d" % (w, h, l)
+            assert np.array_equal(small[0][1], cd) and np.array_equal(big[i][1], cd)
+            assert np.array_equal(small[0][0]["x"], ck["x"])
+
+
 def test_two_contexts_like_stereo():
     left, cpu = make(nfeatures=1200)
     right, _ = make(nfeatures=1200)
