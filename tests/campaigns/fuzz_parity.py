@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--reuse", action="store_true",
-                    help="one context sized 1000 x 800 for all cases (image sizes change from call to call, batches of 1-3)")
+                    help="one context sized 1000 x 800 for all cases (image sizes change from call to call; batches of 1-3, "
+                         "which take the one-launch pyramid, and every fourth case 9-12, which go level by level)")
     a = ap.parse_args()
     import my_orb_slam2_amd as m
     from my_orb_slam2_amd import synth as S
@@ -30,10 +31,12 @@ def main():
     rng = np.random.default_rng(a.seed)
     total_kp = 0
     if a.reuse:
-        gpu = m.ORBextractor(700, 1.2, 8, 20, 7, max_width=1000, max_height=800, max_batch=3)
+        gpu = m.ORBextractor(700, 1.2, 8, 20, 7, max_width=1000, max_height=800, max_batch=12)
         cpu = orc.Extractor(700, 1.2, 8, 20, 7)
         for case in range(a.cases):
             w, h, b = int(rng.integers(70, 1001)), int(rng.integers(70, 801)), int(rng.integers(1, 4))
+            if case % 4 == 3:
+                b = int(rng.integers(9, 13))
             frames = m.synth_batch(5000 + 3 * case, b, w, h)
             if rng.random() < 0.2:
                 frames[0] = m.synth_frame(case, w, h, kind=S.NOISE)
