@@ -158,6 +158,14 @@ int orbx_get_level(orbx_ctx* ctx, int frame, int level, int border, uint8_t* dst
 #define ORBX_BLUR_PATCH_CY 18
 #define ORBX_BLUR_PATCH_CX 23
 int orbx_debug_keypoint_blur(orbx_ctx* ctx, int frame, uint8_t* dst, int cap, int* n);
+/* Host-only check of the work plan of the one-launch pyramid kernel (the kernel small calls use in place of one
+ * launch per cv::resize, src/ORBextractor.cc:1112): builds the plan for an image size and pyramid shape and
+ * verifies that every pixel of every level is written by exactly one tile and that every tile finds the source
+ * pixels of what it computes in its own tile of the level above. Needs no GPU. *ngroups = launches the plan makes
+ * (0: this pyramid shape takes the per-level kernel). tile_w x tile_h = tile on a group's last level,
+ * group_levels = levels per launch; the library itself uses 16, 8, 8. */
+int orbx_debug_check_pyramid_plan(int width, int height, float scale_factor, int nlevels, int tile_w, int tile_h,
+                                  int group_levels, int* ngroups);
 int orbx_debug_candidates(orbx_ctx* ctx, int frame, int level, orbx_keypoint* out, int cap, int* n);
 int orbx_debug_selected(orbx_ctx* ctx, int frame, int level, orbx_keypoint* out, int cap, int* n);
 

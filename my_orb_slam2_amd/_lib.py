@@ -63,6 +63,8 @@ SIGNATURES = {
     "orbx_get_stage_ms": (C.c_int, [_P, _P]),
     "orbx_level_size": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "orbx_get_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t]),
+    "orbx_debug_check_pyramid_plan": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.POINTER(C.c_int)]),
     "orbx_debug_keypoint_blur": (C.c_int, [_P, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "orbx_debug_candidates": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "orbx_debug_selected": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),

@@ -650,6 +650,38 @@ extern "C" int orbx_debug_keypoint_blur(orbx_ctx* c, int frame, uint8_t* dst, in
     return ORBX_OK;
 }
 
+extern "C" int orbx_debug_check_pyramid_plan(int width, int height, float scale_factor, int nlevels, int tile_w,
+                                             int tile_h, int group_levels, int* ngroups) {
+    if (width < 1 || height < 1 || !(scale_factor > 1.0f) || nlevels < 1 || nlevels > ORBX_MAX_LEVELS || tile_w < 4 ||
+        tile_h < 1 || group_levels < 1 || !ngroups) {
+        set_error("orbx_debug_check_pyramid_plan: bad argument");
+        return ORBX_ERR_INVALID;
+    }
+    ScaleTables tab;
+    build_scale_tables(100, scale_factor, nlevels, tab);
+    PyramidGeom g;
+    std::string err;
+    if (!build_geometry(width, height, tab, g, err)) {
+        set_error("%s", err.c_str());
+        return ORBX_ERR_INVALID;
+    }
+    std::vector<HostResizeTab> ht(g.nlevels);
+    ResizeTab tabs[ORBX_MAX_LEVELS] = {};
+    for (int l = 1; l < g.nlevels; l++) {
+        build_resize_table(g.lv[l - 1].w, g.lv[l - 1].h, g.lv[l].w, g.lv[l].h, ht[l]);
+        tabs[l].maxSpan = resize_max_span(ht[l]);
+    }
+    FusedPlan plan;
+    plan_fused_pyramid(g, ht, tabs, tile_w, tile_h, group_levels, plan);
+    *ngroups = (int)plan.groups.size();
+    if (!check_fused_plan(g, ht, plan, err)) {
+        set_error("pyramid plan for %dx%d, scale %g, %d levels: %s", width, height, (double)scale_factor, nlevels,
+                  err.c_str());
+        return ORBX_ERR_STATE;
+    }
+    return ORBX_OK;
+}
+
 extern "C" int orbx_debug_candidates(orbx_ctx* c, int frame, int level, orbx_keypoint* out, int cap, int* n) {
     int rc = check_probe(c, frame, level);
     if (rc) return rc;

@@ -166,6 +166,10 @@ struct HostResizeTab;
 // when a level does not qualify (step between levels above 2, tiles wider than the kernel's lanes).
 void plan_fused_pyramid(const PyramidGeom& g, const std::vector<HostResizeTab>& ht, const ResizeTab* devTabs,
                         int tileW, int tileH, int groupLevels, FusedPlan& plan);
+bool check_fused_plan(const PyramidGeom& g, const std::vector<HostResizeTab>& ht, const FusedPlan& plan,
+                      std::string& err);
+// Largest source-column step inside a group of four destination columns (ResizeTab::maxSpan).
+int resize_max_span(const HostResizeTab& t);
 hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nframes, int iniTh, int minTh,
                              hipStream_t s);
 hipError_t launch_octree(const FrameSet& fs, const PyramidGeom& g, int nframes, hipStream_t s);

@@ -7,6 +7,8 @@
 // BORDER_REFLECT_101 frame around each level is never read by the extractor (FAST stays 16 px
 // inside, the orientation disc has radius 15, rotated pattern points reach 18 px and keypoints
 // sit >= 19 px from the edge), so it is not stored; orbx_get_level() rebuilds it on request.
+#include <cstdio>
+
 #include "orbx_internal.h"
 
 namespace orbx {
@@ -419,6 +421,53 @@ hipError_t launch_pyramid(const FrameSet& fs, const PyramidGeom& g, const Resize
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// Checks the invariants the one-launch kernel relies on: on every level the owned ranges of the tiles partition
+// the level (so each pixel is written exactly once), a tile owns only what it computes, and everything it
+// computes finds both of its source columns / rows inside what the same tile computed one level up.
+bool check_fused_plan(const PyramidGeom& g, const std::vector<HostResizeTab>& ht, const FusedPlan& plan,
+                      std::string& err) {
+    auto fail = [&](const char* what, size_t k, int j, int i) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "%s (group %zu, level %d of it, tile %d)", what, k, j, i);
+        err = buf;
+        return false;
+    };
+    int covered = 0;
+    for (size_t k = 0; k < plan.groups.size(); k++) {
+        const FusedGroup& G = plan.groups[k];
+        if (plan.firstLevel[k] != covered) return fail("groups do not follow one another", k, 0, 0);
+        covered += G.nl;
+        for (int dim = 0; dim < 2; dim++) {
+            const int nt = dim ? G.nty : G.ntx, align = dim ? 1 : 4;
+            const FusedRange* R = plan.ranges.data() + reinterpret_cast<size_t>(dim ? G.rows : G.cols);
+            for (int j = 0; j < G.nl; j++) {
+                const int l = plan.firstLevel[k] + 1 + j;
+                const int n = dim ? g.lv[l].h : g.lv[l].w, nsrc = dim ? g.lv[l - 1].h : g.lv[l - 1].w;
+                const int nup = (n + align - 1) / align * align;
+                const std::vector<int32_t>& ofs = dim ? ht[l].yofs : ht[l].xofs;
+                int next = 0;
+                for (int i = 0; i < nt; i++) {
+                    const FusedRange& r = R[j * nt + i];
+                    if (r.ownLo != next || r.ownHi < r.ownLo) return fail("owned ranges do not tile the level", k, j, i);
+                    next = r.ownHi;
+                    if (r.lo > r.ownLo || r.hi < r.ownHi || r.lo % align || r.hi % align || r.hi > nup || r.lo < 0)
+                        return fail("computed range does not hold the owned one", k, j, i);
+                    if (!dim && r.hi - r.lo > 128) return fail("tile wider than 128 columns", k, j, i);
+                    if (j == 0) continue;
+                    const FusedRange& up = R[(j - 1) * nt + i];
+                    for (int x = r.lo; x < std::min(r.hi, n); x++) {
+                        const int s0 = std::min(std::max(ofs[x], 0), nsrc - 1), s1 = std::min(s0 + 1, nsrc - 1);
+                        if (s0 < up.lo || s1 >= up.hi) return fail("a source lies outside the tile of the level above", k, j, i);
+                    }
+                }
+                if (next != nup) return fail("owned ranges stop short of the level's end", k, j, nt - 1);
+            }
+        }
+    }
+    if (!plan.groups.empty() && covered != g.nlevels - 1) return fail("groups do not cover all levels", 0, 0, 0);
+    return true;
 }
 
 }  // namespace orbx

@@ -177,4 +177,14 @@ void build_resize_table(int sw, int sh, int dw, int dh, HostResizeTab& t) {
     }
 }
 
+int resize_max_span(const HostResizeTab& t) {
+    const size_t n = t.xofs.size(), n4 = (n + 3) / 4 * 4;
+    int maxSpan = 0;
+    for (size_t i = 0; i < n4; i++) {
+        const size_t j = std::min(i, n - 1), j0 = std::min(i & ~(size_t)3, n - 1);
+        maxSpan = std::max(maxSpan, t.xofs[j] - t.xofs[j0]);
+    }
+    return maxSpan;
+}
+
 }  // namespace orbx

@@ -65,3 +65,28 @@ def test_no_gpu_means_error_not_fallback():
     assert e.value.code == -2                            # ORBX_ERR_HIP
     with pytest.raises(m.OrbxError):
         m.HammingMatcher()
+
+
+def test_one_launch_pyramid_plan_covers_every_pixel_once():
+    """Host logic behind the pyramid kernel of small calls: for many image sizes, pyramid steps, level counts and
+    tile shapes the plan must give every pixel of every level to exactly one tile and keep every tile's source
+    pixels inside its own tile of the level above (checked inside the library, which needs no GPU for it)."""
+    from my_orb_slam2_amd._lib import lib
+    rng = np.random.default_rng(5)
+    cases = [(752, 480, 1.2, 8, 16, 8, 8), (1920, 1080, 1.2, 8, 16, 8, 8), (1241, 376, 1.2, 8, 16, 8, 8),
+             (752, 480, 1.2, 8, 64, 32, 4), (333, 250, 1.1, 12, 16, 8, 8), (500, 300, 1.7, 4, 16, 8, 8),
+             (97, 80, 1.2, 8, 16, 8, 8), (4096, 4096, 1.2, 3, 16, 8, 8), (752, 480, 2.0, 4, 16, 8, 8)]
+    for _ in range(400):
+        cases.append((int(rng.integers(40, 2000)), int(rng.integers(40, 1300)),
+                      float(rng.choice([1.05, 1.1, 1.2, 1.25, 1.33, 1.5, 1.7, 2.0])), int(rng.integers(2, 13)),
+                      int(rng.choice([8, 16, 24, 32, 64])), int(rng.choice([1, 4, 8, 16, 32])), int(rng.integers(1, 9))))
+    planned = 0
+    for w, h, scale, nlevels, tw, th, gl in cases:
+        n = C.c_int(-1)
+        rc = lib().orbx_debug_check_pyramid_plan(w, h, scale, nlevels, tw, th, gl, C.byref(n))
+        assert rc == 0, (w, h, scale, nlevels, tw, th, gl, lib().orbx_last_error())
+        planned += n.value > 0
+    assert planned > 300          # most shapes take the one-launch kernel; the rest fall back by design
+    n = C.c_int(-1)
+    assert lib().orbx_debug_check_pyramid_plan(752, 480, 1.2, 8, 16, 8, 8, C.byref(n)) == 0 and n.value == 1
+    assert lib().orbx_debug_check_pyramid_plan(333, 250, 1.1, 12, 16, 8, 8, C.byref(n)) == 0 and n.value == 2
