@@ -257,7 +257,8 @@ __device__ __forceinline__ uint32_t dot4(uint32_t x, uint32_t w, uint32_t acc) {
 
 }  // namespace
 
-// Exclusive prefix of every frame's per-level keypoint counts, and the frame totals the caller receives.
+// Exclusive prefix of every frame's per-level keypoint counts, and the frame totals the caller receives
+// (batched calls; a call of a few frames lets every wave sum the counts itself and saves the launch).
 __global__ __launch_bounds__(64) void sel_prefix_kernel(FrameSet fs, int nlevels, int nframes,
                                                         int32_t* __restrict__ countsOut) {
     const int f = blockIdx.x * 64 + threadIdx.x;
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(64) void sel_prefix_kernel(FrameSet fs, int nlevels
 
 // 22.5 KB of LDS per workgroup lets seven workgroups share a CU; seven waves per SIMD need <= 72 VGPRs, which is
 // why the pattern rows are fetched only after the row pass.
+template <bool OWN_PREFIX>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameSet fs, PyramidGeom g,
                                                                            int blurTaps,
                                                                            orbx_keypoint* __restrict__ kpsOut,
@@ -290,10 +292,34 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     int l = 0;
     while (l + 1 < g.nlevels && slot >= g.lv[l + 1].selBase) l++;
     const int k = slot - g.lv[l].selBase;
-    // position in the frame's output: levels are concatenated in order (:1067-1096); sel_prefix_kernel has
-    // summed the lower levels, so a wave needs two loads instead of one per level
-    const int mine = fs.selCount[(long long)f * g.nlevels + l];
-    const int outIdx = fs.selBefore[(long long)f * g.nlevels + l] + k;
+    // Position in the frame's output: levels are concatenated in order (:1067-1096), so a keypoint sits behind
+    // all keypoints of the lower levels. Batched calls read that number from sel_prefix_kernel's table (two
+    // loads); in a call of a few frames, where one more dependent launch costs more than some scalar work per
+    // wave, the frame's short row of per-level counts is fetched whole and summed here without branches.
+    int before = 0, mine = 0;
+    if (OWN_PREFIX) {
+        const int32_t* cnt = fs.selCount + (long long)f * g.nlevels;
+        int total = 0, c[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) c[i] = i < g.nlevels ? cnt[i] : 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            before += i < l ? c[i] : 0;
+            mine = i == l ? c[i] : mine;
+            total += c[i];
+        }
+        for (int i = 8; i < g.nlevels; i++) {            // pyramids deeper than eight levels: rare
+            const int ci = cnt[i];
+            before += i < l ? ci : 0;
+            mine = i == l ? ci : mine;
+            total += ci;
+        }
+        if (slot == 0 && lane == 0) countsOut[f] = total;  // the frame's keypoint count, as the caller receives it
+    } else {
+        mine = fs.selCount[(long long)f * g.nlevels + l];
+        before = fs.selBefore[(long long)f * g.nlevels + l];
+    }
+    const int outIdx = before + k;
     if (k >= mine || outIdx >= cap) return;
     const LevelGeom& L = g.lv[l];
     uint8_t* R = s_mem + wv * kWaveLds;                                        // raw patch, later Bl
@@ -496,9 +522,14 @@ hipError_t launch_orient_desc(const FrameSet& fs, const PyramidGeom& g, int nfra
                               uint8_t* blDump) {
     // level 0 is read with dword loads like the other levels: the caller of this launcher has made it 4-byte aligned
     if ((uintptr_t)fs.img % 4 || fs.imgRowStride % 4 || fs.imgFrameStride % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sel_prefix_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, fs, g.nlevels, nframes, counts);
     dim3 grid(nframes, (g.totalSel + kWavesPerBlock - 1) / kWavesPerBlock, 1), block(64 * kWavesPerBlock, 1, 1);
-    hipLaunchKernelGGL(orient_desc_kernel, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts, blDump);
+    if (nframes <= 8 && g.totalSel > 0) {
+        hipLaunchKernelGGL(orient_desc_kernel<true>, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts, blDump);
+    } else {
+        hipLaunchKernelGGL(sel_prefix_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, fs, g.nlevels, nframes, counts);
+        if (g.totalSel > 0)
+            hipLaunchKernelGGL(orient_desc_kernel<false>, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts, blDump);
+    }
     return hipGetLastError();
 }
 
