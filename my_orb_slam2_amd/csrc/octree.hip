@@ -15,9 +15,10 @@
 //   - each processed node is replaced by its non-empty children n1..n4, pushed to the front of the
 //     list one by one (:612-652), so the new list is: all children in reverse creation order,
 //     then the surviving old nodes in their old order.
-// Child point counts of every candidate are counted speculatively (LDS atomics), prefix sums give
-// the stopping point and every node's new position, and a second pass over the points re-labels
-// them. Finally each node emits its strongest point, first one on ties (:736-752).
+// Child point counts of every candidate are counted speculatively (LDS atomics) by the same pass that
+// gives the points their node, so they are ready when a round starts; prefix sums give the stopping
+// point and every node's new position, and one pass over the points per round re-labels them and
+// counts for the round after. Finally each node emits its strongest point, first one on ties (:736-752).
 #include "orbx_internal.h"
 
 namespace orbx {
@@ -27,21 +28,29 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kBatch = 4;          // candidates a thread loads before it uses the first (hides the memory latency)
 
+// Inclusive scan over the 64 lanes of a wave with DPP adds (no LDS traffic): shifts by 1, 2, 4, 8 inside each row of
+// 16 lanes, then the totals of rows 0 and 2 are broadcast into rows 1 and 3, and the total of the first half into
+// the second.
+__device__ __forceinline__ int wave_scan_inclusive(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast31 into rows 2 and 3
+    return x;
+}
+
 // Inclusive scan of data[0..n) in place. `part` holds kThreads ints. All threads must call.
-// Each thread owns a run of ceil(n / 256) elements; run totals are scanned inside each wave with
-// lane shuffles and the four wave totals are combined through LDS: two barriers in all.
+// Each thread owns a run of ceil(n / 256) elements (one element in all but the largest quotas); run totals are
+// scanned inside each wave and the four wave totals are combined through LDS: two barriers in all.
 __device__ void block_scan_inclusive(int* data, int n, int* part) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int per = (n + kThreads - 1) / kThreads;
     const int b = min(t * per, n), e = min(b + per, n);
     int s = 0;
     for (int i = b; i < e; i++) s += data[i];
-    int incl = s;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
-    }
+    const int incl = wave_scan_inclusive(s);
     if (lane == 63) part[wv] = incl;
     __syncthreads();
     int run = incl - s;
@@ -80,12 +89,13 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
     short* childPos = sp + 8 * nodeCap;              // [node][4]
     int* ip = reinterpret_cast<int*>(sp + 12 * nodeCap);
     A.cnt = ip; B.cnt = ip + nodeCap;
-    int* cc = ip + 2 * nodeCap;                      // [node][4] speculative child counts
+    int* cc = ip + 2 * nodeCap;                      // [node][4] speculative child counts of the current nodes
     int* rank = ip + 6 * nodeCap;                    // processing rank of a split candidate
     int* order = ip + 7 * nodeCap;                   // node at processing rank r
     int* sinc = ip + 8 * nodeCap;                    // inclusive sum of (children - 1) in processing order
     int* keptPos = ip + 9 * nodeCap;                 // scan of surviving old nodes / new position
-    int* part = ip + 10 * nodeCap;                   // kThreads ints of scan scratch
+    int* ccNext = ip + 10 * nodeCap;                 // [node][4] the same counts for the nodes of the next round
+    int* part = ip + 14 * nodeCap;                   // kThreads ints of scan scratch
     int* sh = part + kThreads;                       // small shared scalars
     // sh[0]=nsplit sh[1]=m sh[2]=nExp
 
@@ -117,33 +127,22 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
             const int pos = keptPos[i] - 1;
             A.x0[pos] = B.x0[i]; A.y0[pos] = B.y0[i]; A.x1[pos] = B.x1[i]; A.y1[pos] = B.y1[i];
             A.cnt[pos] = B.cnt[i];
+            cc[4 * pos] = cc[4 * pos + 1] = cc[4 * pos + 2] = cc[4 * pos + 3] = 0;
         }
     }
     __syncthreads();
-    for (int p = t; p < P; p += kThreads) nid[p] = (uint16_t)(keptPos[nid[p]] - 1);
+    // Every pass that gives the points their node also counts, for nodes with more than one point, how many
+    // fall into each quadrant: the child counts a round needs are ready when it starts.
+    for (int p = t; p < P; p += kThreads) {
+        const int n = keptPos[nid[p]] - 1;
+        nid[p] = (uint16_t)n;
+        if (A.cnt[n] > 1) atomicAdd(&cc[4 * n + quadrant(cand[p], A, n)], 1);
+    }
     __syncthreads();
 
     Nodes cur = A, nxt = B;
     bool careful = false;
     for (int round = 0; round < 4096; round++) {
-        // ---- speculative child counts of every split candidate ----
-        for (int i = t; i < 4 * Lc; i += kThreads) cc[i] = 0;
-        __syncthreads();
-        // (candidates may live in global memory: kBatch independent loads are issued before the first use)
-        for (int p0 = t; p0 < P; p0 += kThreads * kBatch) {
-            int n[kBatch];
-            uint32_t c[kBatch];
-#pragma unroll
-            for (int k = 0; k < kBatch; k++) {
-                const int p = min(p0 + k * kThreads, P - 1);
-                n[k] = nid[p];
-                c[k] = cand[p];
-            }
-#pragma unroll
-            for (int k = 0; k < kBatch; k++)
-                if (p0 + k * kThreads < P && cur.cnt[n[k]] > 1) atomicAdd(&cc[4 * n[k] + quadrant(c[k], cur, n[k])], 1);
-        }
-        __syncthreads();
         // ---- processing order ----
         if (!careful) {
             for (int i = t; i < Lc; i += kThreads) rank[i] = cur.cnt[i] > 1 ? 1 : 0;
@@ -216,6 +215,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
         const int nsplit = sh[0];
         const int C = nsplit > 0 ? sinc[nsplit - 1] + nsplit : 0;   // children created this round
         const int Lnew = Lc - nsplit + C;
+        const bool done = Lnew >= N || Lnew == Lc;     // (:661, :726)
         if (Lnew > nodeCap) {  // cannot happen (Lnew <= max(N+3, 4*nIni)); never write out of bounds
             if (t == 0) *selCountOut = 0;
             return;
@@ -232,6 +232,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
                 const int pos = C + keptPos[i] - 1;
                 nxt.x0[pos] = cur.x0[i]; nxt.y0[pos] = cur.y0[i]; nxt.x1[pos] = cur.x1[i]; nxt.y1[pos] = cur.y1[i];
                 nxt.cnt[pos] = cur.cnt[i];
+                ccNext[4 * pos] = ccNext[4 * pos + 1] = ccNext[4 * pos + 2] = ccNext[4 * pos + 3] = 0;
                 keptPos[i] = pos;
             } else {
                 const int r = rank[i];
@@ -249,6 +250,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
                     nxt.y0[pos] = (short)((q & 2) ? ym : y0);
                     nxt.y1[pos] = (short)((q & 2) ? y1 : ym);
                     nxt.cnt[pos] = cq;
+                    ccNext[4 * pos] = ccNext[4 * pos + 1] = ccNext[4 * pos + 2] = ccNext[4 * pos + 3] = 0;
                     childPos[4 * i + q] = (short)pos;
                     nExp += cq > 1;
                 }
@@ -257,7 +259,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
             }
         }
         __syncthreads();
-        // ---- re-label the points ----
+        // ---- re-label the points (and count them into the quadrants of their new nodes for the next round) ----
         for (int p0 = t; p0 < P; p0 += kThreads * kBatch) {
             int n[kBatch];
             uint32_t c[kBatch];
@@ -271,13 +273,15 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
             for (int k = 0; k < kBatch; k++) {
                 if (p0 + k * kThreads >= P) break;
                 const int kp = keptPos[n[k]];
-                nid[p0 + k * kThreads] = (uint16_t)(kp >= 0 ? kp : childPos[4 * n[k] + quadrant(c[k], cur, n[k])]);
+                const int nn = kp >= 0 ? kp : childPos[4 * n[k] + quadrant(c[k], cur, n[k])];
+                nid[p0 + k * kThreads] = (uint16_t)nn;
+                if (!done && nxt.cnt[nn] > 1) atomicAdd(&ccNext[4 * nn + quadrant(c[k], nxt, nn)], 1);
             }
         }
         __syncthreads();
         const int nExp = sh[2];
         const Nodes tmp = cur; cur = nxt; nxt = tmp;
-        const bool done = Lnew >= N || Lnew == Lc;     // (:661, :726)
+        int* const tc = cc; cc = ccNext; ccNext = tc;
         if (!careful && !done && Lnew + 3 * nExp > N) careful = true;   // (:665)
         Lc = Lnew;
         __syncthreads();
@@ -314,8 +318,8 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
 }  // namespace
 
 size_t octree_lds_bytes(const PyramidGeom& g) {
-    // 12 shorts + 10 ints per node, scan scratch, scalars
-    return (size_t)g.nodeCap * (12 * 2 + 10 * 4) + (kThreads + 8) * 4 + 16;
+    // 12 shorts + 14 ints per node, scan scratch, scalars
+    return (size_t)g.nodeCap * (12 * 2 + 14 * 4) + (kThreads + 8) * 4 + 16;
 }
 
 __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGeom g) {
@@ -341,11 +345,7 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
     int incl = mine;
     {
         const int lane = t & 63, wv = t >> 6;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
+        incl = wave_scan_inclusive(incl);
         if (lane == 63) part[wv] = incl;
         __syncthreads();
         for (int w = 0; w < wv; w++) incl += part[w];
