@@ -32,6 +32,7 @@ class ORBextractor:
         self._last_shape = None
         self._ext_stream = None
         self._inflight = collections.deque()
+        self._call_bufs = None
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
@@ -99,11 +100,16 @@ class ORBextractor:
         if image.strides[1] != 1:
             image = np.ascontiguousarray(image)
         h, w = image.shape
-        kps = np.empty(self._capacity, dtype=KEYPOINT_DTYPE)
-        desc = np.empty((self._capacity, 32), dtype=np.uint8)
-        n = C.c_int(0)
-        check(lib().orbx_extract(self._ctx, np_ptr(image), w, h, image.strides[0], np_ptr(kps), np_ptr(desc),
-                                 self._capacity, C.byref(n)), "orbx_extract")
+        if self._call_bufs is None:
+            # output arrays and their pointers are made once: `a.ctypes` costs microseconds, which matter when the
+            # call itself takes a tenth of a millisecond
+            kps = np.empty(self._capacity, dtype=KEYPOINT_DTYPE)
+            desc = np.empty((self._capacity, 32), dtype=np.uint8)
+            n = C.c_int(0)
+            self._call_bufs = (kps, desc, n, np_ptr(kps), np_ptr(desc), C.byref(n), lib().orbx_extract)
+        kps, desc, n, pk, pd, pn, fn = self._call_bufs
+        n.value = 0
+        check(fn(self._ctx, image.ctypes.data, w, h, image.strides[0], pk, pd, self._capacity, pn), "orbx_extract")
         self._last_shape = (1, h, w)
         return kps[:n.value].copy(), desc[:n.value].copy()
 
