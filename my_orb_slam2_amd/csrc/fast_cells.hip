@@ -21,6 +21,17 @@ namespace orbx {
 
 namespace {
 
+__device__ __forceinline__ int max3u(int a, int b, int c) {
+    int r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int min3u(int a, int b, int c) {
+    int r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // Corner strength of the pixel at p (LDS, row pitch `pitch`): see step 3 above.
 template <int pitch>
 __device__ __forceinline__ int corner_strength(const uint8_t* p) {
@@ -50,16 +61,23 @@ __device__ __forceinline__ int corner_strength(const uint8_t* p) {
         lo3[k] = min(min(c[k], c[(k + 1) & 15]), c[(k + 2) & 15]);
         hi3[k] = max(max(c[k], c[(k + 1) & 15]), c[(k + 2) & 15]);
     }
-    int hiMin = 256, loMax = -1;   // smallest arc maximum, largest arc minimum
+    // An arc of nine is three windows of three: one three-input instruction per arc and polarity, then the sixteen
+    // arc values fold three at a time (written as instructions so that the compiler keeps this shape: left to
+    // itself it shares two-input partial results between arcs and ends up with more instructions).
+    int h9[16], l9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-        const int h0 = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
-        const int h1 = max(max(hi3[k + 1], hi3[(k + 4) & 15]), hi3[(k + 7) & 15]);
-        hiMin = min(min(hiMin, h0), h1);
-        const int l0 = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
-        const int l1 = min(min(lo3[k + 1], lo3[(k + 4) & 15]), lo3[(k + 7) & 15]);
-        loMax = max(max(loMax, l0), l1);
+    for (int k = 0; k < 16; k++) {
+        h9[k] = max3u(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+        l9[k] = min3u(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
     }
+    int hiMin = h9[15], loMax = l9[15];   // smallest arc maximum, largest arc minimum
+#pragma unroll
+    for (int k = 0; k < 14; k += 2) {
+        hiMin = min3u(hiMin, h9[k], h9[k + 1]);
+        loMax = max3u(loMax, l9[k], l9[k + 1]);
+    }
+    hiMin = min(hiMin, h9[14]);
+    loMax = max(loMax, l9[14]);
     return max(v - hiMin, loMax - v);      // darker-arc strength, brighter-arc strength
 }
 
@@ -87,6 +105,14 @@ __device__ __forceinline__ unsigned long long cmp_lt_word1(uint32_t a, uint32_t 
     unsigned long long m;
     asm("v_cmp_lt_u16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_1" : "=s"(m) : "v"(a), "v"(b));
     return m;
+}
+
+// x + (this lane's bit of m): the lane mask goes in as the carry of an add-with-carry.
+__device__ __forceinline__ int add_mask_bit(int x, unsigned long long m) {
+    int r;
+    unsigned long long carryOut;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(carryOut) : "v"(x), "s"(m));
+    return r;
 }
 
 // number of set bits of m below this lane's own
@@ -122,7 +148,8 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellBase) l++;
     const LevelGeom& L = g.lv[l];
     const int c = cell - L.cellBase;
-    const int ci = c / L.nCols, cj = c - ci * L.nCols;
+    // c / nCols without a division (the multiplier of a one-column grid would not fit 32 bits)
+    const int ci = L.nCols == 1 ? c : (int)__umulhi((uint32_t)c, L.colsMagic), cj = c - ci * L.nCols;
 
     int32_t* countOut = fs.cellCount + (long long)f * g.totalCells + cell;
     uint32_t* slotOut = fs.slots + (long long)f * g.totalSlots + L.slotBase + (long long)c * L.slotCap;
@@ -275,7 +302,7 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
             for (int j = 0; j < 4; j++) {
                 const bool pass = __builtin_amdgcn_inverse_ballot_w64(m[j]);
                 if (pass) queue[pos] = (uint16_t)(yx + j);
-                pos += pass;
+                if (j < 3) pos = add_mask_bit(pos, m[j]);          // pos += pass
                 nq += __popcll(m[j]);
             }
             yx += rowsPerIter << 8;

@@ -24,6 +24,7 @@ struct LevelGeom {
     int stride;             // row pitch in bytes inside the pyramid buffer (levels >= 1)
     long long offset;       // byte offset of the level inside one frame's pyramid buffer (levels >= 1)
     int nCols, nRows;       // FAST cell grid (:776-777); 0 when the level is too small for one cell
+    uint32_t colsMagic;     // floor(2^32 / nCols) + 1 for nCols > 1: cell / nCols = mulhi(cell, colsMagic) for any cell index of a level
     int wCell, hCell;       // (:778-779)
     int cellBase;           // first cell of this level in a frame's cell arrays
     int slotCap;            // candidate capacity of one cell

@@ -105,6 +105,7 @@ bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g,
         // than wide; such levels produce no keypoints here.
         if (nCols < 1 || nRows < 1 || nIni < 1) { nCols = nRows = nIni = 0; }
         L.nCols = nCols;
+        L.colsMagic = nCols > 1 ? (uint32_t)((1ull << 32) / (unsigned)nCols + 1) : 0u;   // exact for indices below 2^16
         L.nRows = nRows;
         L.wCell = nCols ? (int)std::ceil(fw / nCols) : 0;
         L.hCell = nRows ? (int)std::ceil(fh / nRows) : 0;
