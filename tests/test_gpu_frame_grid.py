@@ -172,3 +172,38 @@ def test_candidate_lists_longer_than_the_pinned_budget():
     want_n, want, want_prev = orc.search_for_initialization(k1, d1, k2, d2, bounds, want_prev, 2000, 0.9, True)
     n, got = hm.search_for_initialization(k1, d1, k2, d2, start, items, bounds, prev, 2000, 0.9, True)
     assert n == want_n and np.array_equal(got, want) and np.array_equal(prev, want_prev)
+
+
+def test_device_resident_search_edges_and_a_corrupt_device_grid():
+    """Empty frames give no matches; a device grid whose indices point outside frame 2 (something the host cannot
+    check without copying it back) is walked without leaving the arrays: the bad entries are skipped."""
+    import torch
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    ex = m.ORBextractor(500, 1.2, 8, 20, 7)
+    hm = m.HammingMatcher()
+    k1, d1 = ex(m.synth_frame(87))
+    k2, d2 = ex(m.synth_frame(87, right_view=True))
+    start, items = orc.assign_grid(k2, bounds)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    t_d1, t_d2 = t(d1), t(d2)
+    t_k2 = t(k2.view(np.uint8).reshape(-1, 28))
+    prev0 = np.stack([k1["x"], k1["y"]], 1).astype(np.float32).copy()
+    want_n, want, _ = orc.search_for_initialization(k1, d1, k2, d2, bounds, prev0.copy(), 100, 0.9, True)
+    n, got = hm.search_for_initialization_device(k1, t_d1, k2, t_k2, t_d2, t(start), t(items.astype(np.int32)), bounds,
+                                                 prev0.copy())
+    assert n == want_n and np.array_equal(got, want)
+    # no keypoints on one side or the other
+    n, got = hm.search_for_initialization_device(k1, t_d1, k2[:0], t_k2, t_d2, t(start), t(items.astype(np.int32)), bounds,
+                                                 prev0.copy())
+    assert n == 0 and np.all(got == -1) and len(got) == len(k1)
+    n, got = hm.search_for_initialization_device(k1[:0], t_d1, k2, t_k2, t_d2, t(start), t(items.astype(np.int32)), bounds,
+                                                 prev0[:0].copy())
+    assert n == 0 and len(got) == 0
+    # corrupt grid: indices far outside frame 2, negative ones, and cell starts beyond the item array
+    bad_items = items.astype(np.int32).copy()
+    bad_items[::7] = 1 << 20
+    bad_items[3::11] = -5
+    bad_start = start.copy()
+    bad_start[2000:] = 1 << 24
+    n, got = hm.search_for_initialization_device(k1, t_d1, k2, t_k2, t_d2, t(bad_start), t(bad_items), bounds, prev0.copy())
+    assert 0 <= n <= len(k1) and np.all((got >= -1) & (got < len(k2)))
