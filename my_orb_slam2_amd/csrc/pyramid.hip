@@ -59,6 +59,13 @@ __global__ __launch_bounds__(256) void pyr_resize_kernel(const uint8_t* __restri
 // a0 | a1 << 16}, built on the host and loaded once per thread. Needs 4-byte aligned rows and a
 // source/destination ratio <= 2.
 constexpr int kRowsPerThread = 8;
+// A horizontal sum S[sx]*a0 + S[sx+1]*a1 is at most 255 * 2048 < 2^19; its low four bits are dropped.
+constexpr uint32_t kHsumMask = 0x0007FFF0u;
+
+// Bits 32..47 of the product of two values below 2^24 (v_mul_hi_u32_u24, full rate; v_mul_hi_u32 is quarter rate).
+__device__ __forceinline__ uint32_t mulhi24(uint32_t a, uint32_t b) {
+    return __umulhi(a & 0x00FFFFFFu, b & 0x00FFFFFFu);      // the masks tell the compiler which instruction fits
+}
 
 __global__ __launch_bounds__(256) void pyr_resize_dword_kernel(const uint8_t* __restrict__ srcBase,
                                                                long long srcRowStride, long long srcFrameStride,
@@ -88,7 +95,8 @@ __global__ __launch_bounds__(256) void pyr_resize_dword_kernel(const uint8_t* __
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, (int)((long long)sh * srcRowStride), 0x00027000);
     const int o0 = 4 * min(q0, lastDw), o1 = 4 * min(q0 + 1, lastDw), o2 = 4 * min(q0 + 2, lastDw);
 
-    // horizontal pass of one source row for this thread's four columns: (S[sx]*a0 + S[sx+1]*a1) >> 4.
+    // horizontal pass of one source row for this thread's four columns: (S[sx]*a0 + S[sx+1]*a1) >> 4, kept
+    // shifted left by 4 (the low four bits cleared) for the 24-bit multiply of the vertical pass.
     // The weights are never negative (they are (1-f)*2048 and f*2048), so the unsigned dot product is exact.
     auto hrow = [&](int sy, uint32_t (&h)[4]) {
         const int rowOff = sy * (int)srcRowStride;                          // wave-uniform; a level is < 2^31 bytes
@@ -100,17 +108,18 @@ __global__ __launch_bounds__(256) void pyr_resize_dword_kernel(const uint8_t* __
 #pragma unroll
         for (int k = 0; k < 4; k++)
             h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(w1, w0, sel[k])),
-                                          __builtin_bit_cast(us2, aa[k]), 0u, false) >> 4;
+                                          __builtin_bit_cast(us2, aa[k]), 0u, false) & kHsumMask;
     };
     // vertical pass + store of one destination row from the sums of its two source rows
     auto vrow = [&](int dy, uint32_t bb, const uint32_t (&a)[4], const uint32_t (&b)[4]) {
-        const uint32_t b0 = bb << 16, b1 = bb & 0xFFFF0000u;               // weights * 65536 (both <= 2048)
+        const uint32_t b0 = (bb << 12) & 0x00FFF000u, b1 = (bb >> 4) & 0x00FFF000u;   // weights << 12 (both <= 2048)
         uint32_t v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            // ((b0 * h0) >> 16) + ((b1 * h1) >> 16) + 2: the high half of (b << 16) * h is that shifted product.
+            // ((b0 * h0) >> 16) + ((b1 * h1) >> 16) + 2 with h = sum >> 4: (b << 12) * (h << 4) is b * h << 16 and
+            // both factors stay below 2^24, so bits 32.. of the full-rate 24-bit product are that shifted product.
             // The sum >> 2 never leaves [0, 255] (a0 + a1, b0 + b1 <= 2049, weights >= 0), so v < 1024.
-            v[k] = __umulhi(b0, a[k]) + __umulhi(b1, b[k]) + 2u;
+            v[k] = mulhi24(b0, a[k]) + mulhi24(b1, b[k]) + 2u;
         // two sums per dword, one shift for both, then bytes 0 and 2 of each (byte 1 holds the shifted-out bits)
         const uint32_t p01 = (v[0] | (v[1] << 16)) >> 2, p23 = (v[2] | (v[3] << 16)) >> 2;
         *reinterpret_cast<uint32_t*>(dst + (long long)dy * dstRowStride) = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
@@ -196,7 +205,7 @@ __device__ __forceinline__ void resize_strip(const FusedLevel& Lv, int x4, int d
 #pragma unroll
         for (int k = 0; k < 4; k++)
             h[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(w1, w0, sel[k])),
-                                          __builtin_bit_cast(us2, aa[k]), 0u, false) >> 4;
+                                          __builtin_bit_cast(us2, aa[k]), 0u, false) & kHsumMask;
     };
     int cachedSy = -1;
     uint32_t hA[4] = {0, 0, 0, 0}, hB[4] = {0, 0, 0, 0};
@@ -208,10 +217,10 @@ __device__ __forceinline__ void resize_strip(const FusedLevel& Lv, int x4, int d
         if (sy0 != cachedSy) hrow(sy0, up);
         hrow(sy1, lo);
         cachedSy = sy1;
-        const uint32_t b0 = bb << 16, b1 = bb & 0xFFFF0000u;
+        const uint32_t b0 = (bb << 12) & 0x00FFF000u, b1 = (bb >> 4) & 0x00FFF000u;
         uint32_t v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = __umulhi(b0, up[k]) + __umulhi(b1, lo[k]) + 2u;
+        for (int k = 0; k < 4; k++) v[k] = mulhi24(b0, up[k]) + mulhi24(b1, lo[k]) + 2u;
         const uint32_t p01 = (v[0] | (v[1] << 16)) >> 2, p23 = (v[2] | (v[3] << 16)) >> 2;
         store(dy, __builtin_amdgcn_perm(p23, p01, 0x06040200u));
     };
