@@ -752,6 +752,8 @@ struct orbx_matcher {
     bool scaleValid = false;
     hipEvent_t evIn[2] = {nullptr, nullptr};      // "the extractor contexts' work is done"
     hipEvent_t evOut = nullptr;                   // "the matcher has read the contexts' pyramids"
+    std::vector<BowRow> bowRows;                  // kept between calls of the vocabulary-node search for their storage
+    BowReplayScratch bowTmp;
 };
 
 namespace {
@@ -1167,7 +1169,9 @@ extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint
                                   const uint32_t* fv2_nodes, const int32_t* fv2_start, const uint32_t* fv2_items,
                                   int fv2_n, float nnratio, int check_orientation, int32_t* matches,
                                   int* nmatches) {
-    std::vector<BowRow> rows;
+    if (!m) { set_error("orbx_search_by_bow: bad argument"); return ORBX_ERR_INVALID; }
+    const bool kfkf = mode == ORBX_BOW_KEYFRAME_KEYFRAME;
+    std::vector<BowRow>& rows = m->bowRows;
     long long npairs = 0;
     int rc = bow_prepare("orbx_search_by_bow", m, mode, keys1_un, desc1, valid1, n1, fv1_nodes, fv1_start, fv1_items,
                          fv1_n, keys2, desc2, valid2, n2, fv2_nodes, fv2_start, fv2_items, fv2_n, matches, nmatches,
@@ -1180,8 +1184,9 @@ extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     // inputs packed in pinned memory in the layout of the device scratch: one copy in, one copy out
     const size_t oD1 = 0, oD2 = oD1 + up(32 * (size_t)n1), oIt = oD2 + up(32 * (size_t)n2),
-                 oRw = oIt + up(4 * (size_t)nItems2), oDs = oRw + up(sizeof(BowRow) * rows.size()),
-                 total = oDs + up(2 * (size_t)npairs);
+                 oRw = oIt + up(4 * (size_t)nItems2),
+                 oV2 = oRw + up(sizeof(BowRow) * rows.size()), oDs = oV2 + up(kfkf ? (size_t)n2 : 0),
+                 oTp = oDs + up(2 * (size_t)npairs), total = oTp + up(4 * kBowTop * rows.size());
     if ((rc = matcher_scratch(m, total, s))) return rc;
     if ((rc = matcher_pinned(m, total))) return rc;
     uint8_t* base = static_cast<uint8_t*>(m->scratch);
@@ -1189,15 +1194,17 @@ extern "C" int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint
     std::memcpy(m->pin + oD2, desc2, 32 * (size_t)n2);
     std::memcpy(m->pin + oIt, fv2_items, 4 * (size_t)nItems2);
     std::memcpy(m->pin + oRw, rows.data(), sizeof(BowRow) * rows.size());
+    if (kfkf) std::memcpy(m->pin + oV2, valid2, (size_t)n2);
     HIP_TRY(hipMemcpyAsync(base, m->pin, oDs, hipMemcpyHostToDevice, s));
     HIP_TRY(launch_bow_distances((int)rows.size(), reinterpret_cast<const BowRow*>(base + oRw), base + oD1,
-                                 reinterpret_cast<const uint32_t*>(base + oIt), base + oD2,
-                                 reinterpret_cast<uint16_t*>(base + oDs), s));
-    HIP_TRY(hipMemcpyAsync(m->pin + oDs, base + oDs, 2 * (size_t)npairs, hipMemcpyDeviceToHost, s));
+                                 reinterpret_cast<const uint32_t*>(base + oIt), base + oD2, kfkf ? base + oV2 : nullptr,
+                                 reinterpret_cast<uint16_t*>(base + oDs), reinterpret_cast<uint32_t*>(base + oTp), s));
+    HIP_TRY(hipMemcpyAsync(m->pin + oDs, base + oDs, total - oDs, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const uint16_t* dist = reinterpret_cast<const uint16_t*>(m->pin + oDs);
-    *nmatches = replay_search_by_bow(mode, rows, dist, fv2_items, keys1_un, keys2, valid2, n1, n2, nnratio,
-                                     check_orientation != 0, matches);
+    *nmatches = replay_search_by_bow(mode, rows, dist, reinterpret_cast<const uint32_t*>(m->pin + oTp), fv2_items,
+                                     keys1_un, keys2, valid2, n1, n2, nnratio, check_orientation != 0, matches,
+                                     m->bowTmp);
     return ORBX_OK;
 }
 
@@ -1209,7 +1216,9 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher* m, int mode, const orbx_k
                                          const uint32_t* fv2_nodes, const int32_t* fv2_start,
                                          const uint32_t* fv2_items, int fv2_n, float nnratio, int check_orientation,
                                          int32_t* matches, int* nmatches) {
-    std::vector<BowRow> rows;
+    if (!m) { set_error("orbx_search_by_bow_device: bad argument"); return ORBX_ERR_INVALID; }
+    const bool kfkf = mode == ORBX_BOW_KEYFRAME_KEYFRAME;
+    std::vector<BowRow>& rows = m->bowRows;
     long long npairs = 0;
     int rc = bow_prepare("orbx_search_by_bow_device", m, mode, keys1_un, d_desc1, valid1, n1, fv1_nodes, fv1_start,
                          fv1_items, fv1_n, keys2, d_desc2, valid2, n2, fv2_nodes, fv2_start, fv2_items, fv2_n, matches,
@@ -1226,18 +1235,22 @@ extern "C" int orbx_search_by_bow_device(orbx_matcher* m, int mode, const orbx_k
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     // The descriptors are already in HBM. The kernel reads its rows and the right-hand feature lists from pinned
     // host memory and writes the distance rows back into it: one launch and one wait, no copy either way.
-    const size_t oIt = 0, oRw = oIt + up(4 * (size_t)nItems2), oDs = oRw + up(sizeof(BowRow) * rows.size()),
-                 total = oDs + up(2 * (size_t)npairs);
+    const size_t oIt = 0, oRw = oIt + up(4 * (size_t)nItems2), oV2 = oRw + up(sizeof(BowRow) * rows.size()),
+                 oDs = oV2 + up(kfkf ? (size_t)n2 : 0), oTp = oDs + up(2 * (size_t)npairs), total = oTp + up(4 * kBowTop * rows.size());
     if ((rc = matcher_pinned(m, total))) return rc;
     std::memcpy(m->pin + oIt, fv2_items, 4 * (size_t)nItems2);
     std::memcpy(m->pin + oRw, rows.data(), sizeof(BowRow) * rows.size());
+    if (kfkf) std::memcpy(m->pin + oV2, valid2, (size_t)n2);
     HIP_TRY(launch_bow_distances((int)rows.size(), reinterpret_cast<const BowRow*>(m->pin + oRw), d_desc1,
                                  reinterpret_cast<const uint32_t*>(m->pin + oIt), d_desc2,
-                                 reinterpret_cast<uint16_t*>(m->pin + oDs), s));
+                                 kfkf ? m->pin + oV2 : nullptr,
+                                 reinterpret_cast<uint16_t*>(m->pin + oDs),
+                                 reinterpret_cast<uint32_t*>(m->pin + oTp), s));
     HIP_TRY(hipStreamSynchronize(s));
     const uint16_t* dist = reinterpret_cast<const uint16_t*>(m->pin + oDs);
-    *nmatches = replay_search_by_bow(mode, rows, dist, fv2_items, keys1_un, keys2, valid2, n1, n2, nnratio,
-                                     check_orientation != 0, matches);
+    *nmatches = replay_search_by_bow(mode, rows, dist, reinterpret_cast<const uint32_t*>(m->pin + oTp), fv2_items,
+                                     keys1_un, keys2, valid2, n1, n2, nnratio, check_orientation != 0, matches,
+                                     m->bowTmp);
     return ORBX_OK;
 }
 

@@ -222,14 +222,24 @@ hipError_t launch_undistort_grid(int nframes, int cap, const orbx_keypoint* kps,
 struct BowRow {
     int32_t idx1, start2, count2, out;
 };
+constexpr int kBowTop = 4;               // entries of a row's ordered short list (bow_distance_kernel)
+constexpr uint32_t kBowListEnd = 0xFFFFFFFFu, kBowNoList = 0xFFFFFFFEu;
+// valid2 (device-readable, may be null): right-hand features that may be matched; the others stay off the lists.
 hipError_t launch_bow_distances(int nrows, const BowRow* rows, const uint8_t* d1, const uint32_t* items2,
-                                const uint8_t* d2, uint16_t* dist, hipStream_t s);
+                                const uint8_t* d2, const uint8_t* valid2, uint16_t* dist, uint32_t* top,
+                                hipStream_t s);
+// Buffers of the host pass that keep their storage from call to call.
+struct BowReplayScratch {
+    std::vector<uint8_t> matched2;
+    std::vector<std::pair<int, int>> binOf;
+};
 bool build_bow_rows(const uint32_t* nodes1, const int32_t* start1, const uint32_t* items1, int nn1,
                     const uint8_t* valid1, int n1, const uint32_t* nodes2, const int32_t* start2,
                     const uint32_t* items2, int nn2, int n2, std::vector<BowRow>& rows, long long& npairs);
-int replay_search_by_bow(int mode, const std::vector<BowRow>& rows, const uint16_t* dist, const uint32_t* items2,
-                         const orbx_keypoint* k1, const orbx_keypoint* k2, const uint8_t* valid2, int n1, int n2,
-                         float nnratio, bool checkOri, int32_t* matches);
+int replay_search_by_bow(int mode, const std::vector<BowRow>& rows, const uint16_t* dist, const uint32_t* top,
+                         const uint32_t* items2, const orbx_keypoint* k1, const orbx_keypoint* k2,
+                         const uint8_t* valid2, int n1, int n2, float nnratio, bool checkOri, int32_t* matches,
+                         BowReplayScratch& tmp);
 // One windowed search over a frame's grid (Frame::GetFeaturesInArea, src/Frame.cc:365-418). r < 0: skipped.
 // ur is only read when the searched frame has right-image coordinates.
 struct WindowQuery {

@@ -131,12 +131,14 @@ def main():
     nm = C.c_int(0)
     pv = prev.copy()
 
+    init_args = (hm._m, np_ptr(k1), C.c_void_p(t_d1.data_ptr()), len(k1), np_ptr(k2), C.c_void_p(t_k2.data_ptr()),
+                 C.c_void_p(t_d2.data_ptr()), len(k2), C.c_void_p(t_start.data_ptr()), C.c_void_p(t_items.data_ptr()),
+                 0.0, 0.0, 752.0, 480.0, np_ptr(pv), 100, 0.9, 1, np_ptr(out12), C.byref(nm))
+    f_init = lib().orbx_search_for_initialization_device
+
     def init_dev():
         pv[:] = prev
-        rc = lib().orbx_search_for_initialization_device(
-            hm._m, np_ptr(k1), C.c_void_p(t_d1.data_ptr()), len(k1), np_ptr(k2), C.c_void_p(t_k2.data_ptr()),
-            C.c_void_p(t_d2.data_ptr()), len(k2), C.c_void_p(t_start.data_ptr()), C.c_void_p(t_items.data_ptr()),
-            0.0, 0.0, 752.0, 480.0, np_ptr(pv), 100, 0.9, 1, np_ptr(out12), C.byref(nm))
+        rc = f_init(*init_args)
         assert rc == 0
     init_dev()
     assert nm.value == n_gpu
@@ -181,13 +183,19 @@ def main():
             nmb = C.c_int(0)
             v2p = np_ptr(v2) if kw else None
 
-            def bow_c(fn, p1, p2):
-                rc = fn(hm._m, mode, np_ptr(k1), p1, np_ptr(v1), len(k1), np_ptr(a[0]), np_ptr(a[1]), np_ptr(a[2]),
+            def args(p1, p2):
+                return (hm._m, mode, np_ptr(k1), p1, np_ptr(v1), len(k1), np_ptr(a[0]), np_ptr(a[1]), np_ptr(a[2]),
                         len(a[0]), np_ptr(k2), p2, v2p, len(k2), np_ptr(bb[0]), np_ptr(bb[1]), np_ptr(bb[2]), len(bb[0]),
                         0.7, 1, np_ptr(outm), C.byref(nmb))
+            host_args = args(np_ptr(d1), np_ptr(d2))
+            dev_args = args(C.c_void_p(t_d1.data_ptr()), C.c_void_p(t_d2.data_ptr()))
+            f_host, f_dev = lib().orbx_search_by_bow, lib().orbx_search_by_bow_device
+
+            def bow_c(fn, arg):
+                rc = fn(*arg)
                 assert rc == 0 and nmb.value == n_gpu
-            host = lambda: bow_c(lib().orbx_search_by_bow, np_ptr(d1), np_ptr(d2))
-            dev = lambda: bow_c(lib().orbx_search_by_bow_device, C.c_void_p(t_d1.data_ptr()), C.c_void_p(t_d2.data_ptr()))
+            host = lambda: bow_c(f_host, host_args)
+            dev = lambda: bow_c(f_dev, dev_args)
             host(); dev()
             t_host_c = best_of(host, 7, 16)
             t_dev_c = best_of(dev, 7, 16)

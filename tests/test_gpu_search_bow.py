@@ -106,3 +106,51 @@ def test_search_by_bow_edges():
         hm.search_by_bow_device(k1, t1, v1, fv1, k2, t2, bad)
     with pytest.raises(m.OrbxError):
         hm.search_by_bow_device(k1, t1, v1, fv1, k2, t2, (fv2[0], bad_start, fv2[2]))
+
+
+@pytest.mark.parametrize("n_bases,n2", [(8, 600), (3, 70), (40, 3000)])
+def test_search_by_bow_crowded_nodes(n_bases, n2):
+    """Few distinct descriptors, many near copies of each, one or two vocabulary nodes: the closest right-hand
+    features of a row are soon taken by earlier rows, ties in distance are everywhere, and rows are both shorter
+    and much longer than a wave. The visiting order decides every result, so any shortcut in the host pass shows."""
+    import torch
+    rng = np.random.default_rng(100 + n_bases)
+    n1 = 300
+    bases = rng.integers(0, 256, (n_bases, 32), dtype=np.uint8)
+
+    def near_copies(n):
+        d = bases[rng.integers(0, n_bases, n)].copy()
+        for i in range(n):
+            for b in rng.choice(256, rng.integers(0, 7), replace=False):
+                d[i, b >> 3] ^= 1 << (b & 7)
+        return d
+
+    d1, d2 = near_copies(n1), near_copies(n2)
+    k1 = np.zeros(n1, dtype=m.KEYPOINT_DTYPE)
+    k2 = np.zeros(n2, dtype=m.KEYPOINT_DTYPE)
+    k1["angle"] = rng.uniform(0, 360, n1).astype(np.float32)
+    k2["angle"] = rng.uniform(0, 360, n2).astype(np.float32)
+    v1 = np.ones(n1, np.uint8)
+    v2 = (rng.random(n2) < 0.7).astype(np.uint8)
+
+    def fv(n, split):
+        order = rng.permutation(n).astype(np.uint32)
+        if split:
+            cut = n // 3
+            return np.array([5, 9], np.uint32), np.array([0, cut, n], np.int32), order
+        return np.array([5], np.uint32), np.array([0, n], np.int32), order
+
+    hm = m.HammingMatcher(0)
+    t1, t2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
+    total = 0
+    for split in (False, True):
+        fv1, fv2 = fv(n1, split), fv(n2, split)
+        for ratio in (0.6, 0.95):
+            for valid2 in (None, v2):
+                want_n, want = orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, valid2, ratio, False)
+                n, got = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, valid2, ratio, False)
+                assert n == want_n and np.array_equal(got, want)
+                n, got = hm.search_by_bow_device(k1, t1, v1, fv1, k2, t2, fv2, valid2, ratio, False)
+                assert n == want_n and np.array_equal(got, want)
+                total += n
+    assert total > 0
