@@ -754,6 +754,9 @@ struct orbx_matcher {
     hipEvent_t evOut = nullptr;                   // "the matcher has read the contexts' pyramids"
     std::vector<BowRow> bowRows;                  // kept between calls of the vocabulary-node search for their storage
     BowReplayScratch bowTmp;
+    std::vector<WindowQuery> winQueries;          // the same for the initialization search
+    std::vector<int32_t> winQueryIndex;
+    InitReplayScratch initTmp;
 };
 
 namespace {
@@ -1339,6 +1342,79 @@ int window_search_core(orbx_matcher* m, const char* who, const std::vector<Windo
     return ORBX_OK;
 }
 
+// What the initialization search hands through run_window_search to its own host pass.
+struct InitTail {
+    const orbx_keypoint* keys1_un;
+    int n1;
+    const std::vector<int32_t>* queryIndex;       // frame-1 keypoint of each (active) query
+    float* prev_matched;
+    float nnratio;
+    bool checkOri;
+    int32_t* matches12;
+    int* nmatches;
+};
+
+// Staging of the initialization search beyond its caller's own use of the two buffers: the active queries and
+// their keypoint numbers go in through pinned memory, one record per query comes back into it, and the lists
+// stay in the device scratch buffer, n2 entries apart.
+struct InitLayout {
+    int nq;
+    size_t pQ, pIx, pRec, pinBytes, sCd, scratchBytes;
+    InitLayout(int nq_, int n2, size_t pinFree, size_t scratchFree) : nq(nq_) {
+        pQ = up256z(pinFree);
+        pIx = pQ + up256z(sizeof(WindowQuery) * (size_t)nq);
+        pRec = pIx + up256z(4 * (size_t)nq);
+        pinBytes = pRec + up256z(4 * (size_t)kWinStride * (size_t)nq);
+        sCd = up256z(scratchFree);
+        scratchBytes = sCd + 4 * (size_t)nq * (size_t)n2;
+    }
+};
+
+// The initialization search: one launch of window_top_kernel and one wait, then the host pass over the records;
+// a query the records do not settle has its list read from the device.
+int initialization_core(orbx_matcher* m, const char* who, const std::vector<WindowQuery>& queries, const WindowDev& in,
+                        const orbx_keypoint* keys2_un, int n2, float min_x, float min_y, float max_x, float max_y,
+                        const InitLayout& lay, const InitTail& tail) {
+    const int nq = lay.nq;
+    hipStream_t s = m->stream;
+    uint8_t* base = static_cast<uint8_t*>(m->scratch);
+    std::memcpy(m->pin + lay.pQ, queries.data(), sizeof(WindowQuery) * (size_t)nq);
+    std::memcpy(m->pin + lay.pIx, tail.queryIndex->data(), 4 * (size_t)nq);
+    const float invW = static_cast<float>(ORBX_GRID_COLS) / (max_x - min_x);
+    const float invH = static_cast<float>(ORBX_GRID_ROWS) / (max_y - min_y);
+    uint32_t* records = reinterpret_cast<uint32_t*>(m->pin + lay.pRec);
+    uint32_t* cand = reinterpret_cast<uint32_t*>(base + lay.sCd);
+    HIP_TRY(launch_window_top(nq, reinterpret_cast<const WindowQuery*>(m->pin + lay.pQ),
+                              reinterpret_cast<const int32_t*>(m->pin + lay.pIx), in.d1, in.k2, in.d2, in.cellStart,
+                              in.cellItems, min_x, min_y, invW, invH, n2, cand, records, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    bool copyFailed = false;
+    auto fetch = [&](int a, int count) -> const uint32_t* {
+        if (a < 0 || a >= nq || count < 0 || count > n2) return nullptr;
+        m->initTmp.list.resize((size_t)count);
+        if (hipMemcpy(m->initTmp.list.data(), cand + (size_t)a * (size_t)n2, 4 * (size_t)count,
+                      hipMemcpyDeviceToHost) != hipSuccess) {
+            copyFailed = true;
+            return nullptr;
+        }
+        return m->initTmp.list.data();
+    };
+    const int n = replay_search_for_initialization_top(tail.keys1_un, tail.n1, keys2_un, n2, nq,
+                                                       tail.queryIndex->data(), records, fetch, tail.prev_matched,
+                                                       tail.nnratio, tail.checkOri, tail.matches12, m->initTmp);
+    if (n < 0) {
+        for (int i = 0; i < tail.n1; i++) tail.matches12[i] = -1;
+        if (copyFailed) {
+            set_error("%s: reading a candidate list back failed: %s", who, hipGetErrorString(hipGetLastError()));
+            return ORBX_ERR_HIP;
+        }
+        set_error("%s: inconsistent candidate lists", who);
+        return ORBX_ERR_STATE;
+    }
+    *tail.nmatches = n;
+    return ORBX_OK;
+}
+
 long long window_cap_total(const std::vector<WindowQuery>& queries, int nItems) {
     long long active = 0;
     for (const WindowQuery& q : queries) active += q.r >= 0.0f;
@@ -1350,7 +1426,8 @@ long long window_cap_total(const std::vector<WindowQuery>& queries, int nItems) 
 int run_window_search(orbx_matcher* m, const char* who, const std::vector<WindowQuery>& queries, const uint8_t* desc1,
                       const orbx_keypoint* keys2, const uint8_t* desc2, const float* uright2, int n2,
                       const int32_t* cell_start2, const int32_t* cell_items2, float min_x, float min_y, float max_x,
-                      float max_y, std::vector<int32_t>& head, const uint32_t** candHost) {
+                      float max_y, std::vector<int32_t>& head, const uint32_t** candHost,
+                      const InitTail* tail = nullptr) {
     const int n1 = (int)queries.size();
     const int kCells = ORBX_GRID_COLS * ORBX_GRID_ROWS;
     const int nItems = cell_start2[kCells];
@@ -1370,7 +1447,8 @@ int run_window_search(orbx_matcher* m, const char* who, const std::vector<Window
             return ORBX_ERR_INVALID;
         }
     }
-    const long long capTotal = window_cap_total(queries, nItems);
+    const long long capTotal = tail ? (long long)n1 * n2 : window_cap_total(queries, nItems);
+    const int nDesc1 = tail ? tail->n1 : n1;              // the initialization search numbers its queries' descriptors by keypoint
     if (n2 > 0x7FFFFF || capTotal > 0x3FFFFFFF) {
         set_error("%s: too many keypoints (%d queries x %d)", who, n1, n2);
         return ORBX_ERR_INVALID;
@@ -1378,15 +1456,16 @@ int run_window_search(orbx_matcher* m, const char* who, const std::vector<Window
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = m->stream;
     // inputs packed in pinned memory in the layout of the device scratch: one copy in
-    const size_t oD1 = 0, oK2 = oD1 + up256z(32 * (size_t)n1), oD2 = oK2 + up256z(sizeof(orbx_keypoint) * n2),
+    const size_t oD1 = 0, oK2 = oD1 + up256z(32 * (size_t)nDesc1), oD2 = oK2 + up256z(sizeof(orbx_keypoint) * n2),
                  oUr = oD2 + up256z(32 * (size_t)n2), oCs = oUr + up256z(uright2 ? 4 * (size_t)n2 : 0),
                  oCi = oCs + up256z(4 * (size_t)(kCells + 1)), oEnd = oCi + up256z(4 * (size_t)std::max(nItems, 1));
     const WindowCoreLayout lay(n1, capTotal, oEnd, oEnd);
-    int rc = matcher_scratch(m, lay.scratchBytes, s);
+    const InitLayout ilay(n1, n2, oEnd, oEnd);
+    int rc = matcher_scratch(m, tail ? ilay.scratchBytes : lay.scratchBytes, s);
     if (rc) return rc;
-    if ((rc = matcher_pinned(m, lay.pinBytes))) return rc;
+    if ((rc = matcher_pinned(m, tail ? ilay.pinBytes : lay.pinBytes))) return rc;
     uint8_t* base = static_cast<uint8_t*>(m->scratch);
-    std::memcpy(m->pin + oD1, desc1, 32 * (size_t)n1);
+    std::memcpy(m->pin + oD1, desc1, 32 * (size_t)nDesc1);
     std::memcpy(m->pin + oK2, keys2, sizeof(orbx_keypoint) * n2);
     std::memcpy(m->pin + oD2, desc2, 32 * (size_t)n2);
     if (uright2) std::memcpy(m->pin + oUr, uright2, 4 * (size_t)n2);
@@ -1396,18 +1475,21 @@ int run_window_search(orbx_matcher* m, const char* who, const std::vector<Window
     WindowDev in{base + oD1, reinterpret_cast<const orbx_keypoint*>(base + oK2), base + oD2,
                  uright2 ? reinterpret_cast<const float*>(base + oUr) : nullptr,
                  reinterpret_cast<const int32_t*>(base + oCs), reinterpret_cast<const int32_t*>(base + oCi)};
+    if (tail) return initialization_core(m, who, queries, in, keys2, n2, min_x, min_y, max_x, max_y, ilay, *tail);
     return window_search_core(m, who, queries, in, n2, min_x, min_y, max_x, max_y, lay, head, candHost);
 }
 
 // SearchForInitialization's queries: one per frame-1 keypoint of level 0 (src/ORBmatcher.cc:427-431), a window
-// around its previous match, level 0 only (:433).
+// around its previous match, level 0 only (:433); queryIndex[a] = the keypoint of query a.
 void initialization_queries(const orbx_keypoint* keys1_un, int n1, const float* prev_matched, int window_size,
-                            std::vector<WindowQuery>& queries) {
-    queries.resize(n1);
+                            std::vector<WindowQuery>& queries, std::vector<int32_t>& queryIndex) {
+    queries.clear();
+    queryIndex.clear();
     for (int i = 0; i < n1; i++) {
         const int level1 = keys1_un[i].octave;
-        queries[i] = WindowQuery{prev_matched[2 * i], prev_matched[2 * i + 1], level1 > 0 ? -1.0f : (float)window_size,
-                                 0.0f, level1, level1};
+        if (level1 > 0) continue;                                                     // :429-431
+        queries.push_back(WindowQuery{prev_matched[2 * i], prev_matched[2 * i + 1], (float)window_size, 0.0f, level1, level1});
+        queryIndex.push_back(i);
     }
 }
 }  // namespace
@@ -1428,16 +1510,14 @@ extern "C" int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoi
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     if (n1 == 0 || n2 == 0) return ORBX_OK;
     // one query per frame-1 keypoint of level 0 (:427-431): window around its previous match, level 0 only (:433)
-    std::vector<WindowQuery> queries;
-    initialization_queries(keys1_un, n1, prev_matched, window_size, queries);
+    std::vector<WindowQuery>& queries = m->winQueries;
+    initialization_queries(keys1_un, n1, prev_matched, window_size, queries, m->winQueryIndex);
+    if (queries.empty()) return ORBX_OK;
     std::vector<int32_t> head;
     const uint32_t* cand = nullptr;
-    int rc = run_window_search(m, "orbx_search_for_initialization", queries, desc1, keys2_un, desc2, nullptr, n2,
-                               cell_start2, cell_items2, min_x, min_y, max_x, max_y, head, &cand);
-    if (rc) return rc;
-    *nmatches = replay_search_for_initialization(keys1_un, n1, keys2_un, n2, head.data(), head.data() + n1, cand,
-                                                 prev_matched, nnratio, check_orientation != 0, matches12);
-    return ORBX_OK;
+    const InitTail tail{keys1_un, n1, &m->winQueryIndex, prev_matched, nnratio, check_orientation != 0, matches12, nmatches};
+    return run_window_search(m, "orbx_search_for_initialization", queries, desc1, keys2_un, desc2, nullptr, n2,
+                             cell_start2, cell_items2, min_x, min_y, max_x, max_y, head, &cand, &tail);
 }
 
 extern "C" int orbx_search_for_initialization_device(orbx_matcher* m, const orbx_keypoint* keys1_un,
@@ -1457,28 +1537,23 @@ extern "C" int orbx_search_for_initialization_device(orbx_matcher* m, const orbx
     *nmatches = 0;
     for (int i = 0; i < n1; i++) matches12[i] = -1;
     if (n1 == 0 || n2 == 0) return ORBX_OK;
-    std::vector<WindowQuery> queries;
-    initialization_queries(keys1_un, n1, prev_matched, window_size, queries);
-    // the grid stays on the device, so the list is bounded by what any grid of n2 keypoints can hold
-    const long long capTotal = window_cap_total(queries, n2);
-    if (n2 > 0x7FFFFF || capTotal > 0x3FFFFFFF) {
-        set_error("orbx_search_for_initialization_device: too many keypoints (%d queries x %d)", n1, n2);
+    std::vector<WindowQuery>& queries = m->winQueries;
+    initialization_queries(keys1_un, n1, prev_matched, window_size, queries, m->winQueryIndex);
+    const int nq = (int)queries.size();
+    if (nq == 0) return ORBX_OK;
+    if (n2 > 0x7FFFFF || (long long)nq * n2 > 0x3FFFFFFF) {
+        set_error("orbx_search_for_initialization_device: too many keypoints (%d queries x %d)", nq, n2);
         return ORBX_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m->device));
-    const WindowCoreLayout lay(n1, capTotal, 0, 0);
+    const InitLayout lay(nq, n2, 0, 0);
     int rc = matcher_scratch(m, lay.scratchBytes, m->stream);
     if (rc) return rc;
     if ((rc = matcher_pinned(m, lay.pinBytes))) return rc;
     const WindowDev in{d_desc1, d_keys2_un, d_desc2, nullptr, d_cell_start2, d_cell_items2};
-    std::vector<int32_t> head;
-    const uint32_t* cand = nullptr;
-    rc = window_search_core(m, "orbx_search_for_initialization_device", queries, in, n2, min_x, min_y, max_x, max_y,
-                            lay, head, &cand);
-    if (rc) return rc;
-    *nmatches = replay_search_for_initialization(keys1_un, n1, keys2_un, n2, head.data(), head.data() + n1, cand,
-                                                 prev_matched, nnratio, check_orientation != 0, matches12);
-    return ORBX_OK;
+    const InitTail tail{keys1_un, n1, &m->winQueryIndex, prev_matched, nnratio, check_orientation != 0, matches12, nmatches};
+    return initialization_core(m, "orbx_search_for_initialization_device", queries, in, keys2_un, n2, min_x, min_y,
+                               max_x, max_y, lay, tail);
 }
 
 extern "C" int orbx_search_by_projection_frame(orbx_matcher* m, const float* proj_uv, const float* inv_z,

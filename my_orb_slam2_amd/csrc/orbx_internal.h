@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "orbx.h"
@@ -251,6 +253,23 @@ hipError_t launch_window_candidates(int n1, const WindowQuery* queries, const ui
                                     const int32_t* cellItems, float minX, float minY, float invW, float invH,
                                     int n2, int capTotal, int32_t* cursor, int32_t* candCount, int32_t* candOffset,
                                     uint32_t* cand, hipStream_t s);
+// window_top_kernel: per active query {count, kWinTop ordered entries}; see search_init.hip.
+constexpr int kWinTop = 8, kWinStride = kWinTop + 1, kWinThreads = 512;
+constexpr uint32_t kWinListEnd = 0xFFFFFFFFu;
+hipError_t launch_window_top(int nq, const WindowQuery* queries, const int32_t* queryIndex, const uint8_t* d1,
+                             const orbx_keypoint* k2, const uint8_t* d2, const int32_t* cellStart,
+                             const int32_t* cellItems, float minX, float minY, float invW, float invH, int n2,
+                             uint32_t* cand, uint32_t* out, hipStream_t s);
+struct InitReplayScratch {
+    std::vector<int> matchedDistance, matches21;
+    std::vector<std::pair<int, int>> binOf;
+    std::vector<uint32_t> list;
+};
+// Returns the number of matches, or -1 when a record or a list holds an index outside the searched frame.
+int replay_search_for_initialization_top(const orbx_keypoint* k1, int n1, const orbx_keypoint* k2, int n2, int nq,
+                                         const int32_t* queryIndex, const uint32_t* records,
+                                         const std::function<const uint32_t*(int, int)>& fetch, float* prev,
+                                         float nnratio, bool checkOri, int32_t* matches12, InitReplayScratch& tmp);
 int replay_search_by_projection_frame(int npts, const int32_t* candCount, const int32_t* candOffset,
                                       const uint32_t* cand, const float* lastAngle, const uint8_t* hasObs,
                                       const orbx_keypoint* k2, const uint8_t* occupied2, int n2, int maxDist,
@@ -258,9 +277,6 @@ int replay_search_by_projection_frame(int npts, const int32_t* candCount, const 
 int replay_search_by_projection_points(int npts, const int32_t* candCount, const int32_t* candOffset,
                                        const uint32_t* cand, const uint8_t* hasObs, const orbx_keypoint* k2,
                                        const uint8_t* occupied2, int n2, float nnratio, int32_t* match2);
-int replay_search_for_initialization(const orbx_keypoint* k1, int n1, const orbx_keypoint* k2, int n2,
-                                     const int32_t* candCount, const int32_t* candOffset, const uint32_t* cand,
-                                     float* prev, float nnratio, bool checkOri, int32_t* matches12);
 void undistort_point_host(const orbx_camera& cam, float u, float v, float* xo, float* yo);
 
 }  // namespace orbx

@@ -155,17 +155,16 @@ def test_search_for_initialization_on_device_resident_frames():
         assert n2_ == want_n and np.array_equal(got2, want) and np.array_equal(prev, want_prev)
 
 
-def test_candidate_lists_longer_than_the_pinned_budget():
+def test_whole_image_windows():
     """A window that covers the whole image makes every level-0 keypoint of frame 2 a candidate of every level-0
-    query: the packed lists outgrow what comes back in the first round trip and the second path (device list +
-    copy) must give the same answer."""
+    query: millions of candidates in lists of thousands, far more than a wave holds at once."""
     bounds = (0.0, 0.0, 752.0, 480.0)
     ex = m.ORBextractor(5000, 1.2, 8, 20, 7)
     hm = m.HammingMatcher()
     k1, d1 = ex(m.synth_frame(86))
     k2, d2 = ex(m.synth_frame(86, right_view=True))
     n0 = int((k1["octave"] == 0).sum())
-    assert n0 * int((k2["octave"] == 0).sum()) > max(1 << 16, 64 * len(k1))      # really beyond the budget
+    assert n0 * int((k2["octave"] == 0).sum()) > 1 << 20
     start, items = orc.assign_grid(k2, bounds)
     prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32).copy()
     want_prev = prev.copy()
@@ -207,3 +206,50 @@ def test_device_resident_search_edges_and_a_corrupt_device_grid():
     bad_start[2000:] = 1 << 24
     n, got = hm.search_for_initialization_device(k1, t_d1, k2, t_k2, t_d2, t(bad_start), t(bad_items), bounds, prev0.copy())
     assert 0 <= n <= len(k1) and np.all((got >= -1) & (got < len(k2)))
+
+
+@pytest.mark.parametrize("n_bases,n,window", [(6, 500, 400), (2, 300, 60), (30, 1500, 150)])
+def test_search_for_initialization_crowded(n_bases, n, window):
+    """Made-up frames where most descriptors are near copies of a few: nearly every candidate is within TH_LOW,
+    ties in distance are everywhere, and the keypoints matched early keep later ones from their closest
+    candidates. The ordered short lists the kernel returns rarely settle a query here, so the path that reads a
+    query's whole list back is the one that decides; both call forms must still equal the oracle."""
+    import torch
+    rng = np.random.default_rng(500 + n_bases)
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    bases = rng.integers(0, 256, (n_bases, 32), dtype=np.uint8)
+
+    def frame(count):
+        k = np.zeros(count, dtype=m.KEYPOINT_DTYPE)
+        k["x"] = rng.uniform(200, 500, count).astype(np.float32)
+        k["y"] = rng.uniform(100, 400, count).astype(np.float32)
+        k["octave"] = (rng.random(count) < 0.15).astype(np.int32)        # a few above level 0
+        k["angle"] = rng.uniform(0, 360, count).astype(np.float32)
+        d = bases[rng.integers(0, n_bases, count)].copy()
+        for i in range(count):
+            for b in rng.choice(256, rng.integers(0, 12), replace=False):
+                d[i, b >> 3] ^= 1 << (b & 7)
+        return k, d
+
+    k1, d1 = frame(n)
+    k2, d2 = frame(n + 37)
+    start, items = orc.assign_grid(k2, bounds)
+    hm = m.HammingMatcher()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    t_d1, t_d2, t_k2 = t(d1), t(d2), t(k2.view(np.uint8).reshape(-1, 28))
+    t_start, t_items = t(start), t(items.astype(np.int32))
+    prev0 = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    total = 0
+    for ratio in (0.9, 0.6):
+        for check_ori in (True, False):
+            want_n, want, want_prev = orc.search_for_initialization(k1, d1, k2, d2, bounds, prev0.copy(), window, ratio,
+                                                                    check_ori)
+            prev = prev0.copy()
+            n_got, got = hm.search_for_initialization(k1, d1, k2, d2, start, items, bounds, prev, window, ratio, check_ori)
+            assert n_got == want_n and np.array_equal(got, want) and np.array_equal(prev, want_prev)
+            prev = prev0.copy()
+            n_got, got = hm.search_for_initialization_device(k1, t_d1, k2, t_k2, t_d2, t_start, t_items, bounds, prev,
+                                                             window, ratio, check_ori)
+            assert n_got == want_n and np.array_equal(got, want) and np.array_equal(prev, want_prev)
+            total += want_n
+    assert total > 0
