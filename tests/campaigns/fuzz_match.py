@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity of the steps either side of extraction: kNN top-2, ComputeStereoMatches,
-UndistortKeyPoints + AssignFeaturesToGrid, SearchForInitialization, each against the CPU oracle with random
+UndistortKeyPoints + AssignFeaturesToGrid, SearchForInitialization, SearchByBoW, each against the CPU oracle with random
 sizes, settings, cameras and windows. Exits 1 with the failing case on the first difference.
 
     python tests/campaigns/fuzz_match.py [--cases 60] [--seed 1]
@@ -30,7 +30,7 @@ def main():
     from tests import oracle as orc
     rng = np.random.default_rng(a.seed)
     hm = m.HammingMatcher()
-    done = {"knn": 0, "stereo_pairs": 0, "stereo_matches": 0, "grid_frames": 0, "init_matches": 0, "projection_matches": 0, "local_map_matches": 0}
+    done = {"knn": 0, "stereo_pairs": 0, "stereo_matches": 0, "grid_frames": 0, "init_matches": 0, "projection_matches": 0, "local_map_matches": 0, "bow_matches": 0}
 
     for case in range(a.cases):
         # ---- kNN ----
@@ -144,6 +144,38 @@ def main():
         if n != want_n or not np.array_equal(got, want) or not np.array_equal(p_g, want_prev):
             fail("search_for_initialization", dict(case=case, w=w, h=h, nf=nf, idx=idx0, window=window, ratio=ratio, ori=ori))
         done["init_matches"] += n
+        # the same search on device-resident descriptors, keypoints and grid
+        if len(k1) and len(k2):
+            tt = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+            p_d = prev.copy()
+            n, got = hm.search_for_initialization_device(k1, tt(d1), k2, tt(k2.view(np.uint8).reshape(-1, 28)), tt(d2),
+                                                         tt(s2), tt(i2.astype(np.int32) if len(i2) else np.zeros(1, np.int32)),
+                                                         ib, p_d, window, ratio, ori)
+            if n != want_n or not np.array_equal(got, want) or not np.array_equal(p_d, want_prev):
+                fail("search_for_initialization_device", dict(case=case, w=w, h=h, nf=nf, idx=idx0, window=window,
+                                                              ratio=ratio, ori=ori))
+
+        # ---- SearchByBoW, both overloads: a feature's vocabulary node is the top bits of its first descriptor byte ----
+        if len(k1) and len(k2):
+            shift = int(rng.integers(1, 7))
+
+            def feature_vector(d):
+                node = (d[:, 0] >> shift).astype(np.uint32) * 3 + 1
+                ids = np.unique(node)
+                order = [rng.permutation(np.flatnonzero(node == nid)) for nid in ids]
+                starts = np.concatenate([[0], np.cumsum([len(o) for o in order])]).astype(np.int32)
+                return ids.astype(np.uint32), starts, np.concatenate(order).astype(np.uint32)
+            fv1, fv2 = feature_vector(d1), feature_vector(d2)
+            v1 = (rng.random(len(k1)) < 0.8).astype(np.uint8)
+            v2 = (rng.random(len(k2)) < 0.8).astype(np.uint8)
+            for valid2 in (None, v2):
+                want_n, want = orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, valid2, ratio, ori)
+                n, got = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, valid2, ratio, ori)
+                n_d, got_d = hm.search_by_bow_device(k1, tt(d1), v1, fv1, k2, tt(d2), fv2, valid2, ratio, ori)
+                if n != want_n or not np.array_equal(got, want) or n_d != want_n or not np.array_equal(got_d, want):
+                    fail("search_by_bow", dict(case=case, w=w, h=h, nf=nf, idx=idx0, shift=shift, ratio=ratio, ori=ori,
+                                               kfkf=valid2 is not None))
+                done["bow_matches"] += n
 
         # ---- SearchByProjection(current = right view, last = left view): random flow, depths, occupancy ----
         if len(k1) and len(k2):
