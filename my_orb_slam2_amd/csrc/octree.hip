@@ -62,6 +62,37 @@ __device__ void block_scan_inclusive(int* data, int n, int* part) {
     __syncthreads();
 }
 
+// The scan a sweep round needs, with its input made on the fly: node i contributes 1 | (children - 1) << 16 when it
+// holds more than one point (it is split; cc holds its four child counts) and 0 otherwise. data[i] receives the
+// inclusive sums: low half = split nodes up to and including i, high half = the (children - 1) of those. Both stay
+// below 2^16 (the node table has fewer than 2^14 entries). Two barriers; *zeroed is cleared between them.
+__device__ void sweep_scan(const int* cnt, const int* cc, int* data, int n, int* part, int* zeroed) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int per = (n + kThreads - 1) / kThreads;
+    const int b = min(t * per, n), e = min(b + per, n);
+    int s = 0;
+    for (int i = b; i < e; i++) {
+        int v = 0;
+        if (cnt[i] > 1) {
+            const int* c4 = cc + 4 * i;
+            v = 1 | (((c4[0] > 0) + (c4[1] > 0) + (c4[2] > 0) + (c4[3] > 0) - 1) << 16);
+        }
+        data[i] = v;
+        s += v;
+    }
+    const int incl = wave_scan_inclusive(s);
+    if (lane == 63) part[wv] = incl;
+    __syncthreads();
+    if (t == 0) *zeroed = 0;              // (every thread has read the old value before it reached the barrier above)
+    int run = incl - s;
+    for (int w = 0; w < wv; w++) run += part[w];
+    for (int i = b; i < e; i++) {
+        run += data[i];
+        data[i] = run;
+    }
+    __syncthreads();
+}
+
 struct Nodes {
     short* x0;
     short* y0;
@@ -143,16 +174,65 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
     Nodes cur = A, nxt = B;
     bool careful = false;
     for (int round = 0; round < 4096; round++) {
-        // ---- processing order ----
+        int C, Lnew;
+        bool done;
+        // Writes the children of split node i (first child = creation index k) and the table entry of a node that
+        // stays (at position pos) into nxt, and records where the points of node i go.
+        auto emit_split = [&](int i, int k) {
+            const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
+            const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1);
+            int nExp = 0;
+            for (int q = 0; q < 4; q++) {
+                const int cq = cc[4 * i + q];
+                if (cq == 0) continue;
+                const int pos = C - 1 - k;           // each child is pushed to the front
+                k++;
+                nxt.x0[pos] = (short)((q & 1) ? xm : x0);
+                nxt.x1[pos] = (short)((q & 1) ? x1 : xm);
+                nxt.y0[pos] = (short)((q & 2) ? ym : y0);
+                nxt.y1[pos] = (short)((q & 2) ? y1 : ym);
+                nxt.cnt[pos] = cq;
+                ccNext[4 * pos] = ccNext[4 * pos + 1] = ccNext[4 * pos + 2] = ccNext[4 * pos + 3] = 0;
+                childPos[4 * i + q] = (short)pos;
+                nExp += cq > 1;
+            }
+            keptPos[i] = -1;
+            if (nExp) atomicAdd(&sh[2], nExp);
+        };
+        auto emit_kept = [&](int i, int pos) {
+            nxt.x0[pos] = cur.x0[i]; nxt.y0[pos] = cur.y0[i]; nxt.x1[pos] = cur.x1[i]; nxt.y1[pos] = cur.y1[i];
+            nxt.cnt[pos] = cur.cnt[i];
+            ccNext[4 * pos] = ccNext[4 * pos + 1] = ccNext[4 * pos + 2] = ccNext[4 * pos + 3] = 0;
+            keptPos[i] = pos;
+        };
         if (!careful) {
-            for (int i = t; i < Lc; i += kThreads) rank[i] = cur.cnt[i] > 1 ? 1 : 0;
+            // ---- a sweep: every node with more than one point is split, in list order, so one scan over the nodes
+            // gives every split node its rank and the creation index of its first child, and every other node the
+            // number of unsplit nodes before it ----
+            sweep_scan(cur.cnt, cc, rank, Lc, part, &sh[2]);
+            const int tot = Lc ? rank[Lc - 1] : 0;
+            const int m = tot & 0xFFFF;
+            C = (tot >> 16) + m;                         // children created this round
+            Lnew = Lc - m + C;
+            done = Lnew >= N || Lnew == Lc;              // (:661)
+            if (Lnew > nodeCap) {  // cannot happen (Lnew <= max(N+3, 4*nIni)); never write out of bounds
+                if (t == 0) *selCountOut = 0;
+                return;
+            }
+            for (int i = t; i < Lc; i += kThreads) {
+                const int S = rank[i], before = S & 0xFFFF;
+                if (cur.cnt[i] > 1) {
+                    const int* c4 = cc + 4 * i;
+                    const int extra = (c4[0] > 0) + (c4[1] > 0) + (c4[2] > 0) + (c4[3] > 0) - 1;
+                    emit_split(i, (S >> 16) - extra + before - 1);
+                } else {
+                    emit_kept(i, C + i - before);
+                }
+            }
             __syncthreads();
-            block_scan_inclusive(rank, Lc, part);   // rank[i]-1 = position among candidates, list order
-            if (t == 0) sh[1] = Lc ? rank[Lc - 1] : 0;
-            __syncthreads();
-            for (int i = t; i < Lc; i += kThreads)
-                if (cur.cnt[i] > 1) { rank[i] -= 1; order[rank[i]] = i; }
-        } else if (P >= (1 << 20)) {
+        } else {
+        // ---- processing order: by point count, ties in list order ----
+        if (P >= (1 << 20)) {
             // (a node could hold more points than the packed keys below have bits for: compare count and position)
             if (t == 0) sh[1] = 0;
             __syncthreads();
@@ -207,15 +287,13 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
         block_scan_inclusive(sinc, m, part);
         if (t == 0) sh[0] = m;
         __syncthreads();
-        if (careful) {
-            for (int r = t; r < m; r += kThreads)
-                if (Lc + sinc[r] >= N && (r == 0 || Lc + sinc[r - 1] < N)) sh[0] = r + 1;  // first rank reaching N
-            __syncthreads();
-        }
+        for (int r = t; r < m; r += kThreads)
+            if (Lc + sinc[r] >= N && (r == 0 || Lc + sinc[r - 1] < N)) sh[0] = r + 1;  // first rank reaching N (:722)
+        __syncthreads();
         const int nsplit = sh[0];
-        const int C = nsplit > 0 ? sinc[nsplit - 1] + nsplit : 0;   // children created this round
-        const int Lnew = Lc - nsplit + C;
-        const bool done = Lnew >= N || Lnew == Lc;     // (:661, :726)
+        C = nsplit > 0 ? sinc[nsplit - 1] + nsplit : 0;   // children created this round
+        Lnew = Lc - nsplit + C;
+        done = Lnew >= N || Lnew == Lc;     // (:726)
         if (Lnew > nodeCap) {  // cannot happen (Lnew <= max(N+3, 4*nIni)); never write out of bounds
             if (t == 0) *selCountOut = 0;
             return;
@@ -227,38 +305,15 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
         if (t == 0) sh[2] = 0;
         __syncthreads();
         for (int i = t; i < Lc; i += kThreads) {
-            const bool split = cur.cnt[i] > 1 && rank[i] < nsplit;
-            if (!split) {
-                const int pos = C + keptPos[i] - 1;
-                nxt.x0[pos] = cur.x0[i]; nxt.y0[pos] = cur.y0[i]; nxt.x1[pos] = cur.x1[i]; nxt.y1[pos] = cur.y1[i];
-                nxt.cnt[pos] = cur.cnt[i];
-                ccNext[4 * pos] = ccNext[4 * pos + 1] = ccNext[4 * pos + 2] = ccNext[4 * pos + 3] = 0;
-                keptPos[i] = pos;
-            } else {
+            if (cur.cnt[i] > 1 && rank[i] < nsplit) {
                 const int r = rank[i];
-                int k = r > 0 ? sinc[r - 1] + r : 0;   // creation index of this node's first child
-                const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
-                const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1);
-                int nExp = 0;
-                for (int q = 0; q < 4; q++) {
-                    const int cq = cc[4 * i + q];
-                    if (cq == 0) continue;
-                    const int pos = C - 1 - k;           // each child is pushed to the front
-                    k++;
-                    nxt.x0[pos] = (short)((q & 1) ? xm : x0);
-                    nxt.x1[pos] = (short)((q & 1) ? x1 : xm);
-                    nxt.y0[pos] = (short)((q & 2) ? ym : y0);
-                    nxt.y1[pos] = (short)((q & 2) ? y1 : ym);
-                    nxt.cnt[pos] = cq;
-                    ccNext[4 * pos] = ccNext[4 * pos + 1] = ccNext[4 * pos + 2] = ccNext[4 * pos + 3] = 0;
-                    childPos[4 * i + q] = (short)pos;
-                    nExp += cq > 1;
-                }
-                keptPos[i] = -1;
-                if (nExp) atomicAdd(&sh[2], nExp);
+                emit_split(i, r > 0 ? sinc[r - 1] + r : 0);
+            } else {
+                emit_kept(i, C + keptPos[i] - 1);
             }
         }
         __syncthreads();
+        }
         // ---- re-label the points (and count them into the quadrants of their new nodes for the next round) ----
         for (int p0 = t; p0 < P; p0 += kThreads * kBatch) {
             int n[kBatch];
@@ -284,7 +339,6 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
         int* const tc = cc; cc = ccNext; ccNext = tc;
         if (!careful && !done && Lnew + 3 * nExp > N) careful = true;   // (:665)
         Lc = Lnew;
-        __syncthreads();
         if (done) break;
     }
 
