@@ -93,17 +93,21 @@ __device__ void sweep_scan(const int* cnt, const int* cc, int* data, int n, int*
     __syncthreads();
 }
 
+// A node's box is one 8-byte LDS word: x = x0 | y0 << 16, y = x1 | y1 << 16 (coordinates are below 2^16).
 struct Nodes {
-    short* x0;
-    short* y0;
-    short* x1;
-    short* y1;
+    uint2* box;
     int* cnt;
 };
 
+__device__ __forceinline__ uint2 make_box(int x0, int y0, int x1, int y1) {
+    return make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+}
+
 __device__ __forceinline__ int quadrant(uint32_t c, const Nodes& nd, int n) {
-    const int xm = nd.x0[n] + ((nd.x1[n] - nd.x0[n] + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2) (:475)
-    const int ym = nd.y0[n] + ((nd.y1[n] - nd.y0[n] + 1) >> 1);
+    const uint2 b = nd.box[n];
+    const int x0 = (int)(b.x & 0xFFFFu), y0 = (int)(b.x >> 16), x1 = (int)(b.y & 0xFFFFu), y1 = (int)(b.y >> 16);
+    const int xm = x0 + ((x1 - x0 + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2) (:475)
+    const int ym = y0 + ((y1 - y0 + 1) >> 1);
     return (cand_x(c) < xm ? 0 : 1) + (cand_y(c) < ym ? 0 : 2);   // n1, n2, n3, n4 (:507-517)
 }
 
@@ -115,8 +119,8 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
     // ---- carve LDS ----
     Nodes A, B;
     short* sp = reinterpret_cast<short*>(lds);
-    A.x0 = sp; A.y0 = sp + nodeCap; A.x1 = sp + 2 * nodeCap; A.y1 = sp + 3 * nodeCap;
-    B.x0 = sp + 4 * nodeCap; B.y0 = sp + 5 * nodeCap; B.x1 = sp + 6 * nodeCap; B.y1 = sp + 7 * nodeCap;
+    A.box = reinterpret_cast<uint2*>(lds);
+    B.box = A.box + nodeCap;
     short* childPos = sp + 8 * nodeCap;              // [node][4]
     int* ip = reinterpret_cast<int*>(sp + 12 * nodeCap);
     A.cnt = ip; B.cnt = ip + nodeCap;
@@ -134,18 +138,22 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
     const int nIni = L.nIni;
     const int height = (L.h - kBorder) - kBorder;
     for (int i = t; i < nIni; i += kThreads) {
-        B.x0[i] = (short)(int)(L.hX * (float)i);
-        B.x1[i] = (short)(int)(L.hX * (float)(i + 1));
-        B.y0[i] = 0;
-        B.y1[i] = (short)height;
+        B.box[i] = make_box((int)(L.hX * (float)i), 0, (int)(L.hX * (float)(i + 1)), height);
         B.cnt[i] = 0;
     }
     __syncthreads();
-    for (int p = t; p < P; p += kThreads) {
-        int r = (int)((float)cand_x(cand[p]) / L.hX);
-        r = min(max(r, 0), nIni - 1);
-        nid[p] = (uint16_t)r;
-        atomicAdd(&B.cnt[r], 1);
+    for (int p0 = t; p0 < P; p0 += kThreads * kBatch) {
+        uint32_t c[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) c[k] = cand[min(p0 + k * kThreads, P - 1)];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            if (p0 + k * kThreads >= P) break;
+            int r = (int)((float)cand_x(c[k]) / L.hX);
+            r = min(max(r, 0), nIni - 1);
+            nid[p0 + k * kThreads] = (uint16_t)r;
+            atomicAdd(&B.cnt[r], 1);
+        }
     }
     __syncthreads();
     // drop empty roots, keep order
@@ -156,7 +164,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
     for (int i = t; i < nIni; i += kThreads) {
         if (B.cnt[i] > 0) {
             const int pos = keptPos[i] - 1;
-            A.x0[pos] = B.x0[i]; A.y0[pos] = B.y0[i]; A.x1[pos] = B.x1[i]; A.y1[pos] = B.y1[i];
+            A.box[pos] = B.box[i];
             A.cnt[pos] = B.cnt[i];
             cc[4 * pos] = cc[4 * pos + 1] = cc[4 * pos + 2] = cc[4 * pos + 3] = 0;
         }
@@ -164,10 +172,22 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
     __syncthreads();
     // Every pass that gives the points their node also counts, for nodes with more than one point, how many
     // fall into each quadrant: the child counts a round needs are ready when it starts.
-    for (int p = t; p < P; p += kThreads) {
-        const int n = keptPos[nid[p]] - 1;
-        nid[p] = (uint16_t)n;
-        if (A.cnt[n] > 1) atomicAdd(&cc[4 * n + quadrant(cand[p], A, n)], 1);
+    for (int p0 = t; p0 < P; p0 += kThreads * kBatch) {
+        int r[kBatch];
+        uint32_t c[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const int p = min(p0 + k * kThreads, P - 1);
+            r[k] = nid[p];
+            c[k] = cand[p];
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            if (p0 + k * kThreads >= P) break;
+            const int n = keptPos[r[k]] - 1;
+            nid[p0 + k * kThreads] = (uint16_t)n;
+            if (A.cnt[n] > 1) atomicAdd(&cc[4 * n + quadrant(c[k], A, n)], 1);
+        }
     }
     __syncthreads();
 
@@ -179,7 +199,8 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
         // Writes the children of split node i (first child = creation index k) and the table entry of a node that
         // stays (at position pos) into nxt, and records where the points of node i go.
         auto emit_split = [&](int i, int k) {
-            const int x0 = cur.x0[i], y0 = cur.y0[i], x1 = cur.x1[i], y1 = cur.y1[i];
+            const uint2 b = cur.box[i];
+            const int x0 = (int)(b.x & 0xFFFFu), y0 = (int)(b.x >> 16), x1 = (int)(b.y & 0xFFFFu), y1 = (int)(b.y >> 16);
             const int xm = x0 + ((x1 - x0 + 1) >> 1), ym = y0 + ((y1 - y0 + 1) >> 1);
             int nExp = 0;
             for (int q = 0; q < 4; q++) {
@@ -187,10 +208,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
                 if (cq == 0) continue;
                 const int pos = C - 1 - k;           // each child is pushed to the front
                 k++;
-                nxt.x0[pos] = (short)((q & 1) ? xm : x0);
-                nxt.x1[pos] = (short)((q & 1) ? x1 : xm);
-                nxt.y0[pos] = (short)((q & 2) ? ym : y0);
-                nxt.y1[pos] = (short)((q & 2) ? y1 : ym);
+                nxt.box[pos] = make_box((q & 1) ? xm : x0, (q & 2) ? ym : y0, (q & 1) ? x1 : xm, (q & 2) ? y1 : ym);
                 nxt.cnt[pos] = cq;
                 ccNext[4 * pos] = ccNext[4 * pos + 1] = ccNext[4 * pos + 2] = ccNext[4 * pos + 3] = 0;
                 childPos[4 * i + q] = (short)pos;
@@ -200,7 +218,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
             if (nExp) atomicAdd(&sh[2], nExp);
         };
         auto emit_kept = [&](int i, int pos) {
-            nxt.x0[pos] = cur.x0[i]; nxt.y0[pos] = cur.y0[i]; nxt.x1[pos] = cur.x1[i]; nxt.y1[pos] = cur.y1[i];
+            nxt.box[pos] = cur.box[i];
             nxt.cnt[pos] = cur.cnt[i];
             ccNext[4 * pos] = ccNext[4 * pos + 1] = ccNext[4 * pos + 2] = ccNext[4 * pos + 3] = 0;
             keptPos[i] = pos;
@@ -417,7 +435,32 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
     // on other streams share the CU while this latency-bound kernel waits.
     uint32_t* cand = fs.cand + (long long)f * g.totalSlots + L.slotBase;
     uint16_t* nid = fs.nid + (long long)f * g.totalSlots + L.slotBase;
-    for (int c = cb; c < ce; c++) {
+    // A thread's first two cells (all it has on most levels) go together: their first eight entries are requested
+    // before either is stored.
+    int cFrom = cb;
+    if (ce - cb >= 2) {
+        const int n0 = counts[cb], n1 = counts[cb + 1];
+        const uint32_t* s0 = slots + (long long)cb * L.slotCap;
+        const uint32_t* s1 = s0 + L.slotCap;
+        uint32_t v0[8], v1[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            v0[k] = k < n0 ? s0[k] : 0u;
+            v1[k] = k < n1 ? s1[k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < n0) cand[dst + k] = v0[k];
+        for (int k = 8; k < n0; k++) cand[dst + k] = s0[k];
+        dst += n0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < n1) cand[dst + k] = v1[k];
+        for (int k = 8; k < n1; k++) cand[dst + k] = s1[k];
+        dst += n1;
+        cFrom = cb + 2;
+    }
+    for (int c = cFrom; c < ce; c++) {
         const int n = counts[c];
         const uint32_t* src = slots + (long long)c * L.slotCap;
         // eight loads in flight per batch instead of one dependent load per entry
