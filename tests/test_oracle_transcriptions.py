@@ -422,3 +422,189 @@ def test_compute_stereo_matches_against_the_python_transcription():
         assert kept == int((want_ur >= 0).sum())
         matched += kept
     assert matched > 200
+
+
+# ---------------------------------------------------------------- SearchForInitialization
+GRID_COLS, GRID_ROWS = 64, 48                                                        # include/PresetParameters.h
+POPCOUNT = np.array([bin(i).count("1") for i in range(256)], dtype=np.int32)
+
+
+def c_round(v):
+    """std::round on a float: halves away from zero."""
+    v = float(v)
+    return int(math.copysign(math.floor(abs(v) + 0.5), v))
+
+
+class PyFrame:
+    """The parts of Frame the initialisation matcher touches: mvKeysUn, mDescriptors, mGrid and the shared grid
+    constants (src/Frame.cc:131-134, AssignFeaturesToGrid :266-282, PosInGrid :420-430)."""
+
+    def __init__(self, keys, desc, bounds):
+        self.keys, self.desc = keys, desc
+        self.min_x, self.min_y = F(bounds[0]), F(bounds[1])
+        self.inv_w = F(GRID_COLS) / (F(bounds[2]) - F(bounds[0]))
+        self.inv_h = F(GRID_ROWS) / (F(bounds[3]) - F(bounds[1]))
+        self.grid = [[[] for _ in range(GRID_ROWS)] for _ in range(GRID_COLS)]
+        for i in range(len(keys)):
+            pos_x = c_round((F(keys["x"][i]) - self.min_x) * self.inv_w)
+            pos_y = c_round((F(keys["y"][i]) - self.min_y) * self.inv_h)
+            if pos_x < 0 or pos_x >= GRID_COLS or pos_y < 0 or pos_y >= GRID_ROWS:
+                continue
+            self.grid[pos_x][pos_y].append(i)
+
+    def features_in_area(self, x, y, r, min_level, max_level):
+        """Frame::GetFeaturesInArea (src/Frame.cc:365-418)."""
+        x, y, r = F(x), F(y), F(r)
+        out = []
+        min_cx = max(0, int(math.floor((x - self.min_x - r) * self.inv_w)))
+        if min_cx >= GRID_COLS:
+            return out
+        max_cx = min(GRID_COLS - 1, int(math.ceil((x - self.min_x + r) * self.inv_w)))
+        if max_cx < 0:
+            return out
+        min_cy = max(0, int(math.floor((y - self.min_y - r) * self.inv_h)))
+        if min_cy >= GRID_ROWS:
+            return out
+        max_cy = min(GRID_ROWS - 1, int(math.ceil((y - self.min_y + r) * self.inv_h)))
+        if max_cy < 0:
+            return out
+        check_levels = min_level > 0 or max_level >= 0
+        for ix in range(min_cx, max_cx + 1):
+            for iy in range(min_cy, max_cy + 1):
+                for j in self.grid[ix][iy]:
+                    if check_levels:
+                        if self.keys["octave"][j] < min_level:
+                            continue
+                        if max_level >= 0 and self.keys["octave"][j] > max_level:
+                            continue
+                    distx = F(self.keys["x"][j]) - x
+                    disty = F(self.keys["y"][j]) - y
+                    if abs(distx) < r and abs(disty) < r:
+                        out.append(j)
+        return out
+
+
+def py_three_maxima(histo):
+    """ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1652-1693)."""
+    max1 = max2 = max3 = 0
+    ind1 = ind2 = ind3 = -1
+    for i, h in enumerate(histo):
+        s = len(h)
+        if s > max1:
+            max3, max2, max1 = max2, max1, s
+            ind3, ind2, ind1 = ind2, ind1, i
+        elif s > max2:
+            max3, max2 = max2, s
+            ind3, ind2 = ind2, i
+        elif s > max3:
+            max3, ind3 = s, i
+    if F(max2) < F(0.1) * F(max1):
+        ind2 = ind3 = -1
+    elif F(max3) < F(0.1) * F(max1):
+        ind3 = -1
+    return ind1, ind2, ind3
+
+
+def py_search_for_initialization(f1, f2, prev_matched, window, nnratio, check_ori):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:413-530); TH_LOW, HISTO_LENGTH from
+    include/PresetParameters.h:11-13."""
+    TH_LOW, HISTO_LENGTH, INT_MAX = 50, 30, 2**31 - 1
+    n1, n2 = len(f1.keys), len(f2.keys)
+    nmatches = 0
+    matches12 = [-1] * n1
+    rot_hist = [[] for _ in range(HISTO_LENGTH)]
+    factor = F(1.0) / F(HISTO_LENGTH)
+    matched_distance = [INT_MAX] * n2
+    matches21 = [-1] * n2
+    for i1 in range(n1):
+        level1 = int(f1.keys["octave"][i1])
+        if level1 > 0:
+            continue
+        indices2 = f2.features_in_area(prev_matched[i1][0], prev_matched[i1][1], window, level1, level1)
+        if not indices2:
+            continue
+        d1 = f1.desc[i1]
+        best_dist, best_dist2, best_idx2 = INT_MAX, INT_MAX, -1
+        for i2 in indices2:
+            dist = int(POPCOUNT[d1 ^ f2.desc[i2]].sum())                             # DescriptorDistance :1698-1714
+            if matched_distance[i2] <= dist:
+                continue
+            if dist < best_dist:
+                best_dist2, best_dist, best_idx2 = best_dist, dist, i2
+            elif dist < best_dist2:
+                best_dist2 = dist
+        if best_dist <= TH_LOW:
+            if F(best_dist) < F(best_dist2) * F(nnratio):
+                if matches21[best_idx2] >= 0:
+                    matches12[matches21[best_idx2]] = -1
+                    nmatches -= 1
+                matches12[i1] = best_idx2
+                matches21[best_idx2] = i1
+                matched_distance[best_idx2] = best_dist
+                nmatches += 1
+                if check_ori:
+                    rot = F(f1.keys["angle"][i1]) - F(f2.keys["angle"][best_idx2])
+                    if rot < 0.0:
+                        rot = rot + F(360.0)
+                    b = c_round(rot / (F(360) * factor))
+                    if b == HISTO_LENGTH:
+                        b = 0
+                    assert 0 <= b < HISTO_LENGTH
+                    rot_hist[b].append(i1)
+    if check_ori:
+        ind1, ind2, ind3 = py_three_maxima(rot_hist)
+        for i in range(HISTO_LENGTH):
+            if i in (ind1, ind2, ind3):
+                continue
+            for idx1 in rot_hist[i]:
+                if matches12[idx1] >= 0:
+                    matches12[idx1] = -1
+                    nmatches -= 1
+    prev = np.array(prev_matched, dtype=np.float32).copy()
+    for i1 in range(n1):
+        if matches12[i1] >= 0:
+            prev[i1] = (f2.keys["x"][matches12[i1]], f2.keys["y"][matches12[i1]])
+    return nmatches, np.array(matches12, dtype=np.int32), prev
+
+
+def test_search_for_initialization_against_the_python_transcription():
+    """Extracted frames (true matches, a 100-px window) and crowded made-up frames (few distinct descriptors, so
+    the skip rule on vMatchedDistance and the un-matching through vnMatches21 decide most results)."""
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    cases = []
+    ex = orc.Extractor(2000)
+    k1, d1 = ex.extract(m.synth_frame(80))
+    k2, d2 = ex.extract(m.synth_frame(80, right_view=True))
+    cases.append((k1, d1, k2, d2, 100, 0.9))
+    rng = np.random.default_rng(77)
+    bases = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+
+    def frame(count):
+        k = np.zeros(count, dtype=m.KEYPOINT_DTYPE)
+        k["x"] = rng.uniform(-5, 760, count).astype(np.float32)                      # some fall outside the grid
+        k["y"] = rng.uniform(-5, 485, count).astype(np.float32)
+        k["octave"] = (rng.random(count) < 0.2).astype(np.int32)
+        k["angle"] = rng.uniform(0, 360, count).astype(np.float32)
+        d = bases[rng.integers(0, len(bases), count)].copy()
+        for i in range(count):
+            for b in rng.choice(256, rng.integers(0, 10), replace=False):
+                d[i, b >> 3] ^= 1 << (b & 7)
+        return k, d
+    cases.append(frame(300) + frame(340) + (60, 0.9))
+    cases.append(frame(200) + frame(200) + (400, 0.6))
+    total = 0
+    for k1, d1, k2, d2, window, ratio in cases:
+        prev0 = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+        f1, f2 = PyFrame(k1, d1, bounds), PyFrame(k2, d2, bounds)
+        # the grid itself: same cells, same order inside a cell
+        start, items = orc.assign_grid(k2, bounds)
+        for cx in range(GRID_COLS):
+            for cy in range(GRID_ROWS):
+                c = cx * GRID_ROWS + cy
+                assert list(items[start[c]:start[c + 1]]) == f2.grid[cx][cy]
+        for check_ori in (True, False):
+            want_n, want, want_prev = py_search_for_initialization(f1, f2, prev0, window, ratio, check_ori)
+            n, got, prev = orc.search_for_initialization(k1, d1, k2, d2, bounds, prev0.copy(), window, ratio, check_ori)
+            assert n == want_n and np.array_equal(got, want) and np.array_equal(prev, want_prev)
+            total += n
+    assert total > 50
