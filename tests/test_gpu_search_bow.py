@@ -154,3 +154,31 @@ def test_search_by_bow_crowded_nodes(n_bases, n2):
                 assert n == want_n and np.array_equal(got, want)
                 total += n
     assert total > 0
+
+
+def test_search_by_bow_rows_longer_than_the_short_lists_can_index():
+    """One vocabulary node holding more than 65,536 right-hand features: the ordered short list of such a row
+    cannot name its positions in 16 bits, so the host pass must read the whole row."""
+    import torch
+    rng = np.random.default_rng(9)
+    n1, n2 = 5, 70000
+    d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    picks = rng.choice(n2, n1, replace=False)
+    d1 = d2[picks].copy()
+    d1[:, 0] ^= 1                                        # one bit away from its partner
+    d2[picks[0] + 1 if picks[0] + 1 < n2 else 0] = d2[picks[0]]      # a tie for the first row
+    k1 = np.zeros(n1, dtype=m.KEYPOINT_DTYPE)
+    k2 = np.zeros(n2, dtype=m.KEYPOINT_DTYPE)
+    v1 = np.ones(n1, np.uint8)
+    v2 = (rng.random(n2) < 0.9).astype(np.uint8)
+    fv1 = (np.array([4], np.uint32), np.array([0, n1], np.int32), np.arange(n1, dtype=np.uint32))
+    fv2 = (np.array([4], np.uint32), np.array([0, n2], np.int32), rng.permutation(n2).astype(np.uint32))
+    hm = m.HammingMatcher(0)
+    t1, t2 = torch.from_numpy(d1).cuda(), torch.from_numpy(d2).cuda()
+    for valid2 in (None, v2):
+        want_n, want = orc.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, valid2, 0.8, False)
+        n, got = hm.search_by_bow(k1, d1, v1, fv1, k2, d2, fv2, valid2, 0.8, False)
+        assert n == want_n and np.array_equal(got, want)
+        n, got = hm.search_by_bow_device(k1, t1, v1, fv1, k2, t2, fv2, valid2, 0.8, False)
+        assert n == want_n and np.array_equal(got, want)
+        assert want_n >= 3
