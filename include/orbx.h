@@ -299,9 +299,11 @@ int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* keys1_u
 /* The same function (src/ORBmatcher.cc:413-530) for frames whose data never left the GPU: d_desc1 and d_desc2 are
  * the descriptor arrays orbx_extract_batch_device wrote for the two frames, d_keys2_un / d_cell_start2 /
  * d_cell_items2 frame 2's mvKeysUn and grid as orbx_undistort_assign_grid_device left them (device pointers, the
- * slices of one frame; descriptor arrays 16-byte aligned). Nothing is uploaded but the n1 queries (24 bytes
- * each, read by the kernel from pinned host memory) and nothing comes back but the packed candidate lists the
- * kernel writes into pinned host memory: one launch and one wait. keys1_un, keys2_un (host copies of mvKeysUn,
+ * slices of one frame; descriptor arrays 16-byte aligned). Nothing is uploaded but one query per level-0 keypoint
+ * of frame 1 (28 bytes each, read by the kernel from pinned host memory) and nothing comes back but, per query,
+ * the number of its candidates and the eight closest of them in order, written into pinned host memory: one
+ * launch and one wait. The candidate lists themselves stay in device memory; the host pass reads one back only
+ * when those eight do not settle its query. keys1_un, keys2_un (host copies of mvKeysUn,
  * which a Frame holds anyway) feed the order-dependent host pass (octaves, angles, the prev_matched update).
  * The device inputs must be complete, or queued on the matcher's stream, when the call is made; it returns
  * after the result is final. Indices in the device grid that fall outside frame 2 are skipped by the kernel. */
@@ -384,8 +386,9 @@ int orbx_search_by_bow(orbx_matcher* m, int mode, const orbx_keypoint* keys1_un,
 /* orbx_search_by_bow with the two descriptor arrays already on the device (d_desc1, d_desc2: what
  * orbx_extract_batch_device wrote for the two images, 16-byte aligned; complete, or queued on the matcher's stream,
  * when the call is made). Every other argument is a host array with the meaning above. The kernel reads the
- * distance rows' descriptions from pinned host memory and writes the distances back into it, so a call is one
- * launch and one wait with no copy in either direction (src/ORBmatcher.cc:153-293, :532-690). */
+ * distance rows' descriptions from pinned host memory and writes the distances, and each row's four closest
+ * matchable entries in order, back into it, so a call is one launch and one wait with no copy in either direction
+ * (src/ORBmatcher.cc:153-293, :532-690). */
 int orbx_search_by_bow_device(orbx_matcher* m, int mode, const orbx_keypoint* keys1_un, const uint8_t* d_desc1,
                               const uint8_t* valid1, int n1, const uint32_t* fv1_nodes, const int32_t* fv1_start,
                               const uint32_t* fv1_items, int fv1_n, const orbx_keypoint* keys2,

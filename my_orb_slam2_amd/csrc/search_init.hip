@@ -3,11 +3,13 @@
 // ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (:41-123): the windowed searches over the
 // current frame's 64 x 48 grid.
 //
-// The data-parallel part — Frame::GetFeaturesInArea (src/Frame.cc:365-418) for every level-0 keypoint of
-// frame 1 and ORBmatcher::DescriptorDistance (:1698-1714) to every candidate — runs on the GPU, one wave
-// per frame-1 keypoint, and leaves per-keypoint candidate lists (index, distance) in the order the
-// reference visits them, packed one after the other. The rest of the function depends on the order in which frame-1 keypoints are
-// processed (vMatchedDistance, vnMatches21), so it is replayed on the host over those lists.
+// The data-parallel part — Frame::GetFeaturesInArea (src/Frame.cc:365-418) for every query and
+// ORBmatcher::DescriptorDistance (:1698-1714) to every candidate — runs on the GPU and leaves per-query candidate
+// lists (index, distance) in the order the reference visits them. The rest of each function depends on the
+// order in which the queries are processed (vMatchedDistance, vnMatches21, what a feature already holds), so it is
+// replayed on the host. Two kernels: window_candidates_kernel (one wave per query, packed lists returned whole;
+// the two projection searches) and window_top_kernel (one workgroup per query, lists kept on the device, an
+// ordered short list per query returned; the initialization search).
 #include <algorithm>
 #include <cmath>
 #include <functional>
