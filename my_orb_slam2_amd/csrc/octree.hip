@@ -396,6 +396,10 @@ size_t octree_lds_bytes(const PyramidGeom& g) {
 
 __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGeom g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // This kernel waits far more than it computes; when its waves share a SIMD with the compute-bound kernels of
+    // other streams they go first whenever they are ready (a small, repeatable gain in the overlapped arrangement;
+    // the same setting in the resize kernel made that kernel slower).
+    __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x;
     const int f = blockIdx.x, l = blockIdx.y;
     const LevelGeom& L = g.lv[l];
