@@ -292,10 +292,17 @@ __global__ __launch_bounds__(256) void stereo_band_kernel(int cap, const orbx_ke
                                                           const uint4* __restrict__ dr, float maxD, int bandRows,
                                                           uint8_t* __restrict__ work, int32_t* __restrict__ bestIdx,
                                                           int32_t* __restrict__ bestDist) {
+    // A workgroup owns 64 row-neighbouring left keypoints (one per lane, the same in each of its four waves); the
+    // waves share the walk over the right keypoints, a quarter of every 64 each, and merge their bests through LDS.
+    __shared__ unsigned merged[64];
     const int pair = blockIdx.y;
-    const int pos = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pos = blockIdx.x * 64 + lane;
     const int nL = min(nl[pair], cap);
-    if ((pos & ~63) >= nL) return;                  // whole wave past the end (also nL == 0)
+    if (blockIdx.x * 64 >= nL) return;              // whole workgroup past the end (also nL == 0)
+    if (wv == 0) merged[lane] = 100u << 16;         // TH_HIGH (:559), no index
+    __syncthreads();
     const long long o = (long long)pair * cap;
     const StereoSorted S = sorted_of_pair(work, cap, pair);
     const bool live = pos < nL;
@@ -309,23 +316,36 @@ __global__ __launch_bounds__(256) void stereo_band_kernel(int cap, const orbx_ke
     const int jBeg = S.rStart[min(max(rowLo - bandRows, 0), kRowBins)];
     const int jEnd = S.rStart[min(max(rowHi + 1, 0), kRowBins)];
     unsigned best = 100u << 16;                     // TH_HIGH (:559), no index
-    for (int j = jBeg; j < jEnd; j++) {
-        const uint32_t band = S.rBand[j];           // wave-uniform addresses: scalar loads
-        const uint32_t oi = S.rOctIdx[j];
-        const float rx = S.rX[j];
-        const int minr = (int)(short)(band & 0xffffu), maxr = (int)(short)(band >> 16);
-        const int roct = (int)(short)(oi >> 16);
-        const bool pass = maxU >= 0 && row >= minr && row <= maxr &&               // (:556, :548)
-                          roct >= L.octave - 1 && roct <= L.octave + 1 &&          // (:570)
-                          rx >= minU && rx <= maxU;                                // (:575)
-        if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
-        const uint32_t iR = oi & 0xffffu;
-        const uint4 ra = dr[2 * (o + iR)], rb = dr[2 * (o + iR) + 1];
-        const int d = __popc(qa.x ^ ra.x) + __popc(qa.y ^ ra.y) + __popc(qa.z ^ ra.z) + __popc(qa.w ^ ra.w) +
-                      __popc(qb.x ^ rb.x) + __popc(qb.y ^ rb.y) + __popc(qb.z ^ rb.z) + __popc(qb.w ^ rb.w);
-        if (pass) best = min(best, ((unsigned)d << 16) | iR);   // d < 100 or nothing; lowest index wins ties (:580)
+    // The stretch of right keypoints goes 64 at a time: every lane fetches one record and that keypoint's
+    // descriptor (one round of memory latency per 64 candidates), then the wave walks the 64 with the fields
+    // broadcast from the owning lane (v_readlane with a uniform index), so the tests run on scalars as before.
+    for (int j0 = jBeg; j0 < jEnd; j0 += 64) {
+        const int jm = min(j0 + lane, jEnd - 1);
+        const uint32_t bandV = S.rBand[jm], oiV = S.rOctIdx[jm];
+        const float rxV = S.rX[jm];
+        const uint4 raV = dr[2 * (o + (oiV & 0xffffu))], rbV = dr[2 * (o + (oiV & 0xffffu)) + 1];
+        const int n = min(16 * wv + 16, jEnd - j0);
+        for (int u = 16 * wv; u < n; u++) {
+            const uint32_t band = __builtin_amdgcn_readlane(bandV, u), oi = __builtin_amdgcn_readlane(oiV, u);
+            const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rxV), u));
+            const int minr = (int)(short)(band & 0xffffu), maxr = (int)(short)(band >> 16);
+            const int roct = (int)(short)(oi >> 16);
+            const bool pass = maxU >= 0 && row >= minr && row <= maxr &&               // (:556, :548)
+                              roct >= L.octave - 1 && roct <= L.octave + 1 &&          // (:570)
+                              rx >= minU && rx <= maxU;                                // (:575)
+            if (__builtin_amdgcn_ballot_w64(pass) == 0) continue;
+            const uint32_t iR = oi & 0xffffu;
+            const int d = __popc(qa.x ^ __builtin_amdgcn_readlane(raV.x, u)) + __popc(qa.y ^ __builtin_amdgcn_readlane(raV.y, u)) +
+                          __popc(qa.z ^ __builtin_amdgcn_readlane(raV.z, u)) + __popc(qa.w ^ __builtin_amdgcn_readlane(raV.w, u)) +
+                          __popc(qb.x ^ __builtin_amdgcn_readlane(rbV.x, u)) + __popc(qb.y ^ __builtin_amdgcn_readlane(rbV.y, u)) +
+                          __popc(qb.z ^ __builtin_amdgcn_readlane(rbV.z, u)) + __popc(qb.w ^ __builtin_amdgcn_readlane(rbV.w, u));
+            if (pass) best = min(best, ((unsigned)d << 16) | iR);   // d < 100 or nothing; lowest index wins ties (:580)
+        }
     }
-    if (live) {
+    atomicMin(&merged[lane], best);
+    __syncthreads();
+    if (live && wv == 0) {
+        best = merged[lane];
         const int d = (int)(best >> 16);
         bestIdx[o + iL] = d < 100 ? (int)(best & 0xffffu) : -1;
         bestDist[o + iL] = d;
@@ -479,15 +499,44 @@ __global__ __launch_bounds__(256) void stereo_median_cut_kernel(int cap, const i
         __syncthreads();
         return c;
     };
-    int total = 0;
-    count_le(0, total);
-    if (total == 0) return;                       // the reference would index an empty vector here
-    const int want = total / 2 + 1;               // smallest v with #(d <= v) >= rank + 1
     int lo = 0, hi = 121 * 510;                   // largest possible 11x11 SAD of centred bytes
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        int dummy;
-        if (count_le(mid, dummy) >= want) hi = mid; else lo = mid + 1;
+    constexpr int kKeep = 8;                      // values a thread keeps in registers (pairs of up to 2048 keypoints)
+    if (n <= 256 * kKeep) {
+        // the bisection on values read once, with wave sums and one barrier per step
+        __shared__ int s_part[2][4];
+        const int lane = t & 63, wv = t >> 6;
+        int v[kKeep];
+#pragma unroll
+        for (int k = 0; k < kKeep; k++) v[k] = t + 256 * k < n ? sadDist[o + t + 256 * k] : -1;
+        int step = 0;
+        auto block_count_le = [&](int limit) {    // #accepted with dist <= limit
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < kKeep; k++) c += v[k] >= 0 && v[k] <= limit;
+            c = wave_sum_i32(c);
+            if (lane == 0) s_part[step & 1][wv] = c;
+            __syncthreads();
+            const int* p = s_part[step & 1];
+            step++;
+            return p[0] + p[1] + p[2] + p[3];
+        };
+        const int total = block_count_le(hi);
+        if (total == 0) return;                   // the reference would index an empty vector here
+        const int want = total / 2 + 1;           // smallest v with #(d <= v) >= rank + 1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (block_count_le(mid) >= want) hi = mid; else lo = mid + 1;
+        }
+    } else {
+        int total = 0;
+        count_le(0, total);
+        if (total == 0) return;
+        const int want = total / 2 + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int dummy;
+            if (count_le(mid, dummy) >= want) hi = mid; else lo = mid + 1;
+        }
     }
     const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), (float)lo);
     for (int i = t; i < n; i += 256) {
@@ -667,7 +716,7 @@ hipError_t launch_stereo_band(int npairs, int cap, const orbx_keypoint* kl, cons
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int bandRows = 2 * (int)std::ceil(2.0f * maxScale) + 2;   // maxr - minr never exceeds this
-    dim3 grid((cap + 255) / 256, npairs, 1), block(256, 1, 1);
+    dim3 grid((cap + 63) / 64, npairs, 1), block(256, 1, 1);
     hipLaunchKernelGGL(stereo_band_kernel, grid, block, 0, s, cap, kl, reinterpret_cast<const uint4*>(dl), nl,
                        reinterpret_cast<const uint4*>(dr), maxD, bandRows, static_cast<uint8_t*>(work), bestIdx,
                        bestDist);
