@@ -202,10 +202,12 @@ struct StereoSorted {        // per pair, in the matcher's scratch
     float* rX;               // [cap] column
     uint32_t* rOctIdx;       // [cap] octave << 16 | index in the caller's array
     int32_t* lPerm;          // [cap] left keypoint indices sorted by row
+    int32_t* matchCount;     // [1] left keypoints whose band match is close enough for the refinement ...
+    int32_t* matchList;      // [cap] ... and their indices, in no particular order
 };
 
 __device__ __forceinline__ StereoSorted sorted_of_pair(uint8_t* work, int cap, int pair) {
-    const size_t per = sizeof(int32_t) * ((size_t)kRowBins + 1 + 4 * (size_t)cap);
+    const size_t per = sizeof(int32_t) * ((size_t)kRowBins + 2 + 5 * (size_t)cap);
     uint8_t* p = work + per * pair;
     StereoSorted v;
     v.rStart = reinterpret_cast<int32_t*>(p);
@@ -213,6 +215,8 @@ __device__ __forceinline__ StereoSorted sorted_of_pair(uint8_t* work, int cap, i
     v.rX = reinterpret_cast<float*>(v.rBand + cap);
     v.rOctIdx = reinterpret_cast<uint32_t*>(v.rX + cap);
     v.lPerm = reinterpret_cast<int32_t*>(v.rOctIdx + cap);
+    v.matchCount = v.lPerm + cap;
+    v.matchList = v.matchCount + 1;
     return v;
 }
 
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(256) void stereo_sort_kernel(int cap, const orbx_ke
     const int nL = min(nl[pair], cap), nR = min(nr[pair], cap);
     const long long o = (long long)pair * cap;
     const StereoSorted S = sorted_of_pair(work, cap, pair);
+    if (t == 0) *S.matchCount = 0;                 // the band search fills the list
     // ---- right side: key = first row of the band (:524-526) ----
     for (int i = t; i <= kRowBins; i += 256) hist[i] = 0;
     __syncthreads();
@@ -286,6 +291,9 @@ __global__ __launch_bounds__(256) void stereo_sort_kernel(int cap, const orbx_ke
     scan_rows(hist, part);
     for (int i = t; i < nL; i += 256) S.lPerm[atomicAdd(&hist[min(max((int)kl[o + i].y, 0), kRowBins - 1)], 1)] = i;
 }
+
+constexpr int kStereoRefineDist = (100 + 50) / 2;   // thOrbDist = (TH_HIGH + TH_LOW) / 2 (src/Frame.cc:508)
+constexpr int kRefineBlocks = 64;                   // workgroups per pair in the refinement
 
 __global__ __launch_bounds__(256) void stereo_band_kernel(int cap, const orbx_keypoint* __restrict__ kl,
                                                           const uint4* __restrict__ dl, const int32_t* __restrict__ nl,
@@ -349,6 +357,7 @@ __global__ __launch_bounds__(256) void stereo_band_kernel(int cap, const orbx_ke
         const int d = (int)(best >> 16);
         bestIdx[o + iL] = d < 100 ? (int)(best & 0xffffu) : -1;
         bestDist[o + iL] = d;
+        if (d < kStereoRefineDist) S.matchList[atomicAdd(S.matchCount, 1)] = iL;   // (src/Frame.cc:589)
     }
 }
 
@@ -367,7 +376,7 @@ __device__ __forceinline__ int wave_sum_i32(int x) {
 // band match is closer than (TH_HIGH + TH_LOW) / 2, slide an 11x11 window +-5 px along the row of the
 // right pyramid level, keep the offset with the smallest sum of absolute differences of the
 // centre-subtracted patches, fit a parabola through its neighbours and turn the sub-pixel column into
-// uRight and depth. One wave per left keypoint: a lane owns two of the 121 window positions, the eleven
+// uRight and depth. One wave per listed left keypoint: a lane owns two of the 121 window positions, the eleven
 // sums are wave reductions, everything after them is wave-uniform. sadDist receives the winning SAD (or -1).
 __global__ __launch_bounds__(256) void stereo_refine_kernel(int cap, PyramidView left, PyramidView right,
                                                             const orbx_keypoint* __restrict__ kl,
@@ -378,16 +387,28 @@ __global__ __launch_bounds__(256) void stereo_refine_kernel(int cap, PyramidView
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ invScale, float bf, float maxD,
                                                             float* __restrict__ uRight, float* __restrict__ depth,
-                                                            int32_t* __restrict__ sadDist) {
+                                                            int32_t* __restrict__ sadDist,
+                                                            uint8_t* __restrict__ work) {
     const int pair = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (iL >= cap) return;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long o = (long long)pair * cap;
-    float outU = -1.0f, outZ = -1.0f;
-    int outD = -1;
-    const int thOrbDist = (100 + 50) / 2;               // (TH_HIGH + TH_LOW) / 2 (:508)
-    if (iL < min(nl[pair], cap) && bestDist[o + iL] < thOrbDist && bestIdx[o + iL] >= 0) {
+    const int n = min(nl[pair], cap);
+    const StereoSorted S = sorted_of_pair(work, cap, pair);
+    // what is not refined has no match (its band match was too far, or there was none)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cap; i += kRefineBlocks * 256)
+        if (!(i < n && bestDist[o + i] < kStereoRefineDist)) {
+            uRight[o + i] = -1.0f;
+            depth[o + i] = -1.0f;
+            sadDist[o + i] = -1;
+        }
+    // the left keypoints the band search listed, one per wave and turn
+    const int count = *S.matchCount;
+    for (int j = blockIdx.x * 4 + wv; j < count; j += kRefineBlocks * 4) {
+        const int iL = S.matchList[j];
+        float outU = -1.0f, outZ = -1.0f;
+        int outD = -1;
+        {
         const orbx_keypoint L = kl[o + iL];
         const int oct = min(max(L.octave, 0), left.nlevels - 1);
         const float uR0 = kr[o + bestIdx[o + iL]].x;
@@ -403,30 +424,35 @@ __global__ __launch_bounds__(256) void stereo_refine_kernel(int cap, PyramidView
                             cr - Lr - w >= 0 && cr + Lr + w < B.w;
         if (!(iniu < 0 || endu >= (float)B.w) && inside) {     // (:612-613)
             const uint8_t* pa = A.base + (long long)pair * A.frameStride + (long long)cv * A.rowStride + cu;
-            const uint8_t* pb = B.base + (long long)pair * B.frameStride + (long long)cv * B.rowStride + cr;
             // window positions lane and lane + 64 (row-major 11 x 11; position 60 is the centre); lanes past
             // 120 repeat position 120 with weight 0
             const int i0 = lane, i1 = min(lane + 64, 120);
             const int dy0 = i0 / 11 - w, dx0 = i0 - (dy0 + w) * 11 - w;
             const int dy1 = i1 / 11 - w, dx1 = i1 - (dy1 + w) * 11 - w;
             const bool two = lane + 64 <= 120;
-            const int cL = pa[0];
-            const int a0 = (int)pa[(long long)dy0 * A.rowStride + dx0] - cL;
-            const int a1 = (int)pa[(long long)dy1 * A.rowStride + dx1] - cL;
-            const uint8_t* rb0 = pb + (long long)dy0 * B.rowStride + dx0;
-            const uint8_t* rb1 = pb + (long long)dy1 * B.rowStride + dx1;
-            int rv0[11], rv1[11];
+            const int l0 = pa[(long long)dy0 * A.rowStride + dx0], l1 = pa[(long long)dy1 * A.rowStride + dx1];
+            // The eleven right-image bytes a position meets as the window slides are consecutive: three dwords
+            // through a buffer resource over the level (byte offsets of any alignment; the twelfth byte may lie
+            // one past the level's last row, where the resource returns zero instead of touching memory).
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t*>(B.base + (long long)pair * B.frameStride), 0, (int)((long long)B.h * B.rowStride),
+                0x00027000);
+            const int off0 = (cv + dy0) * (int)B.rowStride + cr + dx0 - Lr, off1 = (cv + dy1) * (int)B.rowStride + cr + dx1 - Lr;
+            uint32_t r0[3], r1[3];
 #pragma unroll
-            for (int k = 0; k < 11; k++) {              // all loads first: their latencies overlap
-                rv0[k] = rb0[k - Lr];
-                rv1[k] = rb1[k - Lr];
+            for (int q = 0; q < 3; q++) {
+                r0[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off0 + 4 * q, 0, 0);
+                r1[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off1 + 4 * q, 0, 0);
             }
+            const int cL = __builtin_amdgcn_readlane(l0, 60);       // position 60 is the window's centre
+            const int a0 = l0 - cL, a1 = l1 - cL;
             int dists[11];
             int best = INT32_MAX, bestInc = 0;
 #pragma unroll
             for (int k = 0; k < 11; k++) {
-                const int cR = pb[k - Lr];               // wave-uniform
-                const int part = abs(a0 - (rv0[k] - cR)) + (two ? abs(a1 - (rv1[k] - cR)) : 0);
+                const int v0 = (int)((r0[k >> 2] >> (8 * (k & 3))) & 0xFFu), v1 = (int)((r1[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                const int cR = __builtin_amdgcn_readlane(v0, 60);   // IR(cv, cr + k - Lr): the centre lane's own byte
+                const int part = abs(a0 - (v0 - cR)) + (two ? abs(a1 - (v1 - cR)) : 0);
                 const int sad = wave_sum_i32(part);
                 dists[k] = sad;
                 if (sad < best) { best = sad; bestInc = k - Lr; }           // float compare of exact integers (:622)
@@ -457,10 +483,11 @@ __global__ __launch_bounds__(256) void stereo_refine_kernel(int cap, PyramidView
             }
         }
     }
-    if (lane == 0) {
-        uRight[o + iL] = outU;
-        depth[o + iL] = outZ;
-        sadDist[o + iL] = outD;
+        if (lane == 0) {
+            uRight[o + iL] = outU;
+            depth[o + iL] = outZ;
+            sadDist[o + iL] = outD;
+        }
     }
 }
 
@@ -701,7 +728,7 @@ hipError_t launch_ratio_test(int64_t nq, const int32_t* d1, const int32_t* d2, i
 }
 
 size_t stereo_band_scratch_bytes(int npairs, int cap) {
-    return sizeof(int32_t) * ((size_t)kRowBins + 1 + 4 * (size_t)cap) * (size_t)npairs;
+    return sizeof(int32_t) * ((size_t)kRowBins + 2 + 5 * (size_t)cap) * (size_t)npairs;
 }
 
 // maxScale: the largest scale factor (a band is 2 * scale rows either side of the keypoint).
@@ -727,10 +754,11 @@ hipError_t launch_stereo_refine(int npairs, int cap, const PyramidView& left, co
                                 const orbx_keypoint* kl, const int32_t* nl, const orbx_keypoint* kr,
                                 const int32_t* bestIdx, const int32_t* bestDist, const float* scale,
                                 const float* invScale, float bf, float maxD, float* uRight, float* depth,
-                                int32_t* sadDist, hipStream_t s) {
+                                int32_t* sadDist, void* work, hipStream_t s) {
     if (npairs <= 0 || cap <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stereo_refine_kernel, dim3((cap + 3) / 4, npairs, 1), dim3(256), 0, s, cap, left, right,
-                       kl, nl, kr, bestIdx, bestDist, scale, invScale, bf, maxD, uRight, depth, sadDist);
+    hipLaunchKernelGGL(stereo_refine_kernel, dim3(kRefineBlocks, npairs, 1), dim3(256), 0, s, cap, left, right,
+                       kl, nl, kr, bestIdx, bestDist, scale, invScale, bf, maxD, uRight, depth, sadDist,
+                       static_cast<uint8_t*>(work));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(stereo_median_cut_kernel, dim3(npairs), dim3(256), 0, s, cap, nl, sadDist, uRight, depth);

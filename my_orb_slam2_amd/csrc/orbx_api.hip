@@ -1073,7 +1073,7 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* lef
     pyramid_view(left, lv);
     pyramid_view(right, rv);
     HIP_TRY(launch_stereo_refine(npairs, cap, lv, rv, d_kl, d_nl, d_kr, bestIdx, bestDist, m->scale,
-                                 m->scale + ORBX_MAX_LEVELS, bf, maxD, d_uright, d_depth, sad, s));
+                                 m->scale + ORBX_MAX_LEVELS, bf, maxD, d_uright, d_depth, sad, m->scratch, s));
     HIP_TRY(hipEventRecord(m->evOut, s));
     for (int i = 0; i < 2; i++) {
         HIP_TRY(hipStreamWaitEvent(side[i]->stream, m->evOut, 0));

@@ -214,7 +214,7 @@ hipError_t launch_stereo_refine(int npairs, int cap, const PyramidView& left, co
                                 const orbx_keypoint* kl, const int32_t* nl, const orbx_keypoint* kr,
                                 const int32_t* bestIdx, const int32_t* bestDist, const float* scale,
                                 const float* invScale, float bf, float maxD, float* uRight, float* depth,
-                                int32_t* sadDist, hipStream_t s);
+                                int32_t* sadDist, void* work, hipStream_t s);
 
 hipError_t launch_undistort_grid(int nframes, int cap, const orbx_keypoint* kps, const int32_t* counts,
                                  orbx_camera cam, float minX, float minY, float invW, float invH,
