@@ -53,11 +53,12 @@ constexpr int kRowsAlloc = 44;          // 43 patch rows, staged in fours; Bl ro
 constexpr int kRPitch = 48;             // bytes per raw row (12 dwords)
 constexpr int kCx = 23;                 // LDS column of the keypoint
 constexpr int kTPitch = 44;             // bytes per row of Bl (columns 0..43 of the patch)
-constexpr int kTDw = 40;                // dwords per packed row pair of T: column groups 1..10 only
 constexpr int kTPairs = 22;             // row pairs of T (43 rows)
+constexpr int kTItems = 191;            // (row pair, column group) cells of T that the pattern's disc needs
+constexpr int kTOffset = 43 * kRPitch;  // T starts on the raw patch's spare row 43 (read only into the unused half of T's last pair)
 constexpr int kBlRows = 37;             // blurred rows: patch rows 3..39
 constexpr int kWavesPerBlock = 4;
-constexpr int kWaveLds = kRowsAlloc * kRPitch + kTPairs * kTDw * 4;  // 2112 + 3520 bytes
+constexpr int kWaveLds = kTOffset + kTItems * 16;   // 2064 + 3056 = 5120 bytes: eight four-wave workgroups per CU
 constexpr int kHIters = 3, kVIters = 3; // 64-item rounds of the row pass and of the column pass
 static_assert(kBlRows == kBlurPatchRows && kTPitch == kBlurPatchPitch && kPR - 3 == kBlurPatchCy && kCx == kBlurPatchCx,
               "the probe's patch shape is the kernel's");
@@ -109,40 +110,80 @@ constexpr bool rowsum_group_needed(int r, int gg) {
         if (blur_group_needed(y, gg)) return true;
     return false;
 }
+// T holds, for every needed (row pair j, column group gg), one 16-byte cell: the packed sums of rows 2j, 2j+1 in
+// the group's four columns. Cells of one group are consecutive in j (the pairs a group needs are a contiguous run,
+// the disc being convex), so the four pairs a column-pass item reads are 16 bytes apart; the groups are stored in
+// the order kTGroupOrder, found by search: with it the cells that neighbouring lanes (neighbouring groups of one
+// pair) touch fall into different 16-byte bank groups, so the 16-byte LDS accesses do not collide.
+constexpr int kTGroupOrder[10] = {2, 4, 3, 5, 10, 1, 8, 6, 7, 9};
+struct TLayout {
+    int lo[11], hi[11], start[11];      // per group: first and last needed pair, first cell
+    int cells;
+};
+constexpr TLayout make_t_layout() {
+    TLayout t{};
+    for (int gg = 1; gg <= 10; gg++) {
+        t.lo[gg] = kTPairs;
+        t.hi[gg] = -1;
+        for (int j = 0; j < kTPairs; j++)
+            if (rowsum_group_needed(2 * j, gg) || rowsum_group_needed(2 * j + 1, gg)) {
+                if (j < t.lo[gg]) t.lo[gg] = j;
+                t.hi[gg] = j;
+            }
+    }
+    int at = 0;
+    for (int k = 0; k < 10; k++) {
+        const int gg = kTGroupOrder[k];
+        t.start[gg] = at;
+        at += t.hi[gg] - t.lo[gg] + 1;
+    }
+    t.cells = at;
+    return t;
+}
+constexpr TLayout kTLayout = make_t_layout();
+static_assert(kTLayout.cells == kTItems, "T layout and its size disagree");
+constexpr int t_cell_offset(int j, int gg) { return 16 * (kTLayout.start[gg] + j - kTLayout.lo[gg]); }
+
 // Work items. Row pass: patch row pair j, group gg -> (byte offset in R of the dword left of the group in
-// row 2j) | (byte offset in T of the pair's four dwords) << 16. Column pass: blurred row pair p, group gg ->
-// (byte offset in T of pair p's dwords) | (byte offset in Bl of row 2p's dword) << 16. Spare slots repeat
-// item 0 (same inputs, same stores).
+// row 2j) | (byte offset in T of the cell) << 16. Column pass: blurred row pair p, group gg ->
+// (byte offset in T of pair p's cell; pairs p+1 .. p+3 follow it) | (byte offset in Bl of row 2p's dword) << 16.
+// Spare slots repeat item 0 (same inputs, same stores).
 struct ItemTables {
     uint32_t h[kHIters * 64];
     uint32_t v[kVIters * 64];
     int nh, nv;
+    bool ok;
 };
 constexpr ItemTables make_item_tables() {
     ItemTables t{};
     int nh = 0, nv = 0;
+    bool ok = true;
     for (int j = 0; j < kTPairs; j++)
         for (int gg = 1; gg <= 10; gg++)
             if (rowsum_group_needed(2 * j, gg) || rowsum_group_needed(2 * j + 1, gg)) {
+                ok = ok && j >= kTLayout.lo[gg] && j <= kTLayout.hi[gg];
                 if (nh < kHIters * 64)
-                    t.h[nh] = (uint32_t)(2 * j * kRPitch + (gg - 1) * 4) | (uint32_t)((j * kTDw + 4 * (gg - 1)) * 4) << 16;
+                    t.h[nh] = (uint32_t)(2 * j * kRPitch + (gg - 1) * 4) | (uint32_t)t_cell_offset(j, gg) << 16;
                 nh++;
             }
     for (int p = 0; 2 * p < kBlRows; p++)
         for (int gg = 1; gg <= 10; gg++)
             if (blur_group_needed(2 * p, gg) || blur_group_needed(2 * p + 1, gg)) {
+                ok = ok && p >= kTLayout.lo[gg] && p + 3 <= kTLayout.hi[gg];      // all four pairs are stored
                 if (nv < kVIters * 64)
-                    t.v[nv] = (uint32_t)((p * kTDw + 4 * (gg - 1)) * 4) | (uint32_t)(2 * p * kTPitch + 4 * gg) << 16;
+                    t.v[nv] = (uint32_t)t_cell_offset(p, gg) | (uint32_t)(2 * p * kTPitch + 4 * gg) << 16;
                 nv++;
             }
     t.nh = nh;
     t.nv = nv;
+    t.ok = ok;
     for (int i = nh; i < kHIters * 64; i++) t.h[i] = t.h[0];
     for (int i = nv; i < kVIters * 64; i++) t.v[i] = t.v[0];
     return t;
 }
 constexpr ItemTables kItems = make_item_tables();
 static_assert(kItems.nh <= kHIters * 64 && kItems.nv <= kVIters * 64, "work item tables overflow");
+static_assert(kItems.nh == kTItems && kItems.ok, "a work item points outside the stored part of T");
 __device__ const ItemTables c_items = make_item_tables();
 
 
@@ -323,7 +364,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
     if (k >= mine || outIdx >= cap) return;
     const LevelGeom& L = g.lv[l];
     uint8_t* R = s_mem + wv * kWaveLds;                                        // raw patch, later Bl
-    uint8_t* Tb = R + kRowsAlloc * kRPitch;                                    // packed row sums
+    uint8_t* Tb = R + kTOffset;                                                // packed row sums
     uint32_t* R32 = reinterpret_cast<uint32_t*>(R);
 
     // work items of both blur passes (independent of everything else: their latency hides behind the staging)
@@ -450,7 +491,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameS
             uint4 e = make_uint4(32768u, 32768u, 32768u, 32768u), o = e;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint4 t = *reinterpret_cast<const uint4*>(tp + r * kTDw * 4);
+                const uint4 t = *reinterpret_cast<const uint4*>(tp + r * 16);
                 const us2 a = __builtin_bit_cast(us2, we[r]), b = __builtin_bit_cast(us2, wo[r]);
                 e.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), a, e.x, false);
                 e.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), a, e.y, false);
