@@ -57,8 +57,8 @@ constexpr int kTPairs = 22;             // row pairs of T (43 rows)
 constexpr int kTItems = 191;            // (row pair, column group) cells of T that the pattern's disc needs
 constexpr int kTOffset = 43 * kRPitch;  // T starts on the raw patch's spare row 43 (read only into the unused half of T's last pair)
 constexpr int kBlRows = 37;             // blurred rows: patch rows 3..39
-constexpr int kWavesPerBlock = 4;
-constexpr int kWaveLds = kTOffset + kTItems * 16;   // 2064 + 3056 = 5120 bytes: eight four-wave workgroups per CU
+constexpr int kWavesPerBlock = 2;
+constexpr int kWaveLds = kTOffset + kTItems * 16;   // 2064 + 3056 = 5120 bytes: 32 waves per CU
 constexpr int kHIters = 3, kVIters = 3; // 64-item rounds of the row pass and of the column pass
 static_assert(kBlRows == kBlurPatchRows && kTPitch == kBlurPatchPitch && kPR - 3 == kBlurPatchCy && kCx == kBlurPatchCx,
               "the probe's patch shape is the kernel's");
@@ -312,8 +312,9 @@ __global__ __launch_bounds__(64) void sel_prefix_kernel(FrameSet fs, int nlevels
     countsOut[f] = run;
 }
 
-// 22.5 KB of LDS per workgroup lets seven workgroups share a CU; seven waves per SIMD need <= 72 VGPRs, which is
-// why the pattern rows are fetched only after the row pass.
+// 5120 bytes of LDS per wave let 32 waves share a CU (eight per SIMD, which need <= 64 VGPRs: why the pattern rows
+// are fetched only after the row pass). Waves are independent; two per workgroup measured best with other
+// kernels running beside this one (smaller pieces fit the gaps those leave sooner), four and one slightly worse.
 template <bool OWN_PREFIX>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameSet fs, PyramidGeom g,
                                                                            int blurTaps,
