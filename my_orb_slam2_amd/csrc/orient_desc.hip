@@ -57,7 +57,6 @@ constexpr int kTPairs = 22;             // row pairs of T (43 rows)
 constexpr int kTItems = 191;            // (row pair, column group) cells of T that the pattern's disc needs
 constexpr int kTOffset = 43 * kRPitch;  // T starts on the raw patch's spare row 43 (read only into the unused half of T's last pair)
 constexpr int kBlRows = 37;             // blurred rows: patch rows 3..39
-constexpr int kWavesPerBlock = 2;
 constexpr int kWaveLds = kTOffset + kTItems * 16;   // 2064 + 3056 = 5120 bytes: 32 waves per CU
 constexpr int kHIters = 3, kVIters = 3; // 64-item rounds of the row pass and of the column pass
 static_assert(kBlRows == kBlurPatchRows && kTPitch == kBlurPatchPitch && kPR - 3 == kBlurPatchCy && kCx == kBlurPatchCx,
@@ -313,20 +312,20 @@ __global__ __launch_bounds__(64) void sel_prefix_kernel(FrameSet fs, int nlevels
 }
 
 // 5120 bytes of LDS per wave let 32 waves share a CU (eight per SIMD, which need <= 64 VGPRs: why the pattern rows
-// are fetched only after the row pass). Waves are independent; two per workgroup measured best with other
-// kernels running beside this one (smaller pieces fit the gaps those leave sooner), four and one slightly worse.
-template <bool OWN_PREFIX>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void orient_desc_kernel(FrameSet fs, PyramidGeom g,
+// are fetched only after the row pass). Waves are independent, so the workgroup size (WAVES) is free: see
+// launch_orient_desc.
+template <bool OWN_PREFIX, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, PyramidGeom g,
                                                                            int blurTaps,
                                                                            orbx_keypoint* __restrict__ kpsOut,
                                                                            uint8_t* __restrict__ descOut, int cap,
                                                                            int32_t* __restrict__ countsOut,
                                                                            uint8_t* __restrict__ blDump) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_mem[kWavesPerBlock * kWaveLds];
+    __shared__ __attribute__((aligned(16))) uint8_t s_mem[WAVES * kWaveLds];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: keeps the set-up scalar
     const int f = blockIdx.x;                     // frame-fastest grid: one frame per XCD
-    const int slot = blockIdx.y * kWavesPerBlock + wv;    // index into the frame's selected regions
+    const int slot = blockIdx.y * WAVES + wv;             // index into the frame's selected regions
     if (slot >= g.totalSel) return;               // the waves of a block never synchronise with each other
     // fetched together with the counts below (the slot exists even when it holds no keypoint), so the patch
     // loads wait for one round trip instead of two
@@ -564,13 +563,22 @@ hipError_t launch_orient_desc(const FrameSet& fs, const PyramidGeom& g, int nfra
                               uint8_t* blDump) {
     // level 0 is read with dword loads like the other levels: the caller of this launcher has made it 4-byte aligned
     if ((uintptr_t)fs.img % 4 || fs.imgRowStride % 4 || fs.imgFrameStride % 4) return hipErrorInvalidValue;
-    dim3 grid(nframes, (g.totalSel + kWavesPerBlock - 1) / kWavesPerBlock, 1), block(64 * kWavesPerBlock, 1, 1);
+    // Waves per workgroup, from measurements with three contexts in flight: on 752x480 frames two waves are 2-3 %
+    // ahead of four (smaller pieces fit sooner into what the other streams' kernels leave free), on 1241x376 the
+    // two tie, on 1920x1080 four are 6-13 % ahead (the four keypoints of a workgroup are neighbours in the
+    // quadtree's order and share patch rows in L1, which matters once level 0 no longer sits in L2).
+    const bool large = (long long)g.lv[0].w * g.lv[0].h > 600000;
+    auto launch = [&](auto kernel, int waves) {
+        hipLaunchKernelGGL(kernel, dim3(nframes, (g.totalSel + waves - 1) / waves, 1), dim3(64 * waves, 1, 1), 0, s, fs, g,
+                           blurTaps, kps, desc, cap, counts, blDump);
+    };
     if (nframes <= 8 && g.totalSel > 0) {
-        hipLaunchKernelGGL(orient_desc_kernel<true>, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts, blDump);
+        if (large) launch(orient_desc_kernel<true, 4>, 4); else launch(orient_desc_kernel<true, 2>, 2);
     } else {
         hipLaunchKernelGGL(sel_prefix_kernel, dim3((nframes + 63) / 64), dim3(64), 0, s, fs, g.nlevels, nframes, counts);
-        if (g.totalSel > 0)
-            hipLaunchKernelGGL(orient_desc_kernel<false>, grid, block, 0, s, fs, g, blurTaps, kps, desc, cap, counts, blDump);
+        if (g.totalSel > 0) {
+            if (large) launch(orient_desc_kernel<false, 4>, 4); else launch(orient_desc_kernel<false, 2>, 2);
+        }
     }
     return hipGetLastError();
 }
