@@ -21,23 +21,29 @@ namespace orbx {
 
 namespace {
 
-__device__ __forceinline__ int max3u(int a, int b, int c) {
-    int r;
-    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+// Three-input minimum / maximum of both 16-bit halves at once (gfx950's packed half-float forms). The halves hold
+// 0x6400 | n, the half-float 1024 + n, for n in 0..255: consecutive integers there, so these are exact integer
+// minima and maxima.
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ int min3u(int a, int b, int c) {
-    int r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
 // Corner strength of the pixel at p (LDS, row pitch `pitch`): see step 3 above.
+// With d_k = v - c_k: max over arcs of min(d) = v - min over arcs of max(c), and min over arcs of max(d) =
+// v - max over arcs of min(c), so the sixteen differences are never formed; and an arc's maximum of c is 255 minus
+// its minimum of 255 - c, so one network of minima over the pairs (c, 255 - c), one pair per dword, serves both
+// polarities: an arc of nine is three windows of three (one three-input instruction per window and per arc), and
+// the sixteen arc values fold three at a time into (largest arc minimum, 255 - smallest arc maximum).
 template <int pitch>
 __device__ __forceinline__ int corner_strength(const uint8_t* p) {
     const int v = p[0];
-    // With d_k = v - c_k: max over arcs of min(d) = v - min over arcs of max(c), and
-    // min over arcs of max(d) = v - max over arcs of min(c); so the sixteen differences are never formed.
     int c[16];
     c[0] = p[3 * pitch];
     c[1] = p[3 * pitch + 1];
@@ -55,29 +61,22 @@ __device__ __forceinline__ int corner_strength(const uint8_t* p) {
     c[13] = p[pitch - 3];
     c[14] = p[2 * pitch - 2];
     c[15] = p[3 * pitch - 1];
-    int lo3[16], hi3[16];
+    // low half 0x6400 + c, high half 0x6400 + 255 - c: 0x64FF6400 + c - (c << 16), one 24-bit multiply-add
+    const int kHalves = 0x64FF6400, kSpread = -0xFFFF;
+    uint32_t w[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo3[k] = min(min(c[k], c[(k + 1) & 15]), c[(k + 2) & 15]);
-        hi3[k] = max(max(c[k], c[(k + 1) & 15]), c[(k + 2) & 15]);
-    }
-    // An arc of nine is three windows of three: one three-input instruction per arc and polarity, then the sixteen
-    // arc values fold three at a time (written as instructions so that the compiler keeps this shape: left to
-    // itself it shares two-input partial results between arcs and ends up with more instructions).
-    int h9[16], l9[16];
+    for (int k = 0; k < 16; k++) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(w[k]) : "v"(c[k]), "s"(kSpread), "v"(kHalves));
+    uint32_t m3[16], m9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        h9[k] = max3u(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
-        l9[k] = min3u(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
-    }
-    int hiMin = h9[15], loMax = l9[15];   // smallest arc maximum, largest arc minimum
+    for (int k = 0; k < 16; k++) m3[k] = pk_min3(w[k], w[(k + 1) & 15], w[(k + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 14; k += 2) {
-        hiMin = min3u(hiMin, h9[k], h9[k + 1]);
-        loMax = max3u(loMax, l9[k], l9[k + 1]);
-    }
-    hiMin = min(hiMin, h9[14]);
-    loMax = max(loMax, l9[14]);
+    for (int k = 0; k < 16; k++) m9[k] = pk_min3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+    uint32_t best = m9[15];
+#pragma unroll
+    for (int k = 0; k < 14; k += 2) best = pk_max3(best, m9[k], m9[k + 1]);
+    best = pk_max3(best, m9[14], m9[14]);
+    const int loMax = (int)(best & 0xFFFFu) - 0x6400;          // largest arc minimum
+    const int hiMin = 255 + 0x6400 - (int)(best >> 16);        // smallest arc maximum
     return max(v - hiMin, loMax - v);      // darker-arc strength, brighter-arc strength
 }
 
