@@ -3,15 +3,20 @@
 // src/ORBmatcher.cc:204-229) and the descriptor half of Frame::ComputeStereoMatches
 // (src/Frame.cc:503-586).
 //
-// kNN kernel: one thread owns one query descriptor in 8 VGPRs. All 64 lanes of a wave walk the same
-// database row at the same time, so the row address is wave-uniform and the row arrives through
-// scalar loads into SGPRs; one pair costs 8 v_xor_b32 + 8 v_bcnt_u32_b32 (the popcount
-// instruction adds its accumulator for free); the three VALU ops that maintain the running best two
-// are skipped for groups of rows that cannot change them.
-// The two best are kept as 32-bit keys (distance << 23 | row offset inside the chunk): taking
-// min / median-of-3 on keys reproduces the reference's strict `<` updates, i.e. the lowest row
-// index wins ties for the best and the second best is the second order statistic of the distances.
-// No MFMA: this is integer bit-counting, not a dense float contraction.
+// kNN kernel: the distances come off the matrix pipe. With a query's bits as s = +1 / -1 (bit 0 / 1) and a
+// database row's bits as b = 0 / 1,
+//     sum_k s[k] * b[k] = |row| - 2 <query, row> = D(query, row) - |query|,
+// so a 32 x 32 tile of dot products over K = 256 ranks the 32 rows for each of 32 queries by Hamming distance,
+// exactly (every product is 0 or +-1 and every sum a small integer). The bits are expanded to FP4 nibbles
+// (1.0 = 0b0010, -1.0 = 0b1010) and a tile is four v_mfma_f32_32x32x64_f8f6f4 with both operands FP4: 128 matrix-pipe
+// cycles for 1024 pairs, against 1072 VALU-issue cycles for the same pairs as xor + popcount.
+// Queries are the N side and stay in registers as ready operands (NQB blocks of 32 per wave); database rows are the
+// M side, 32 per step, expanded through a 256-entry table in LDS. A lane of the 32 x 32 result holds 16 rows of ONE
+// query, so "can any of these rows enter this query's best two" is a three-level min tree and one compare, and the
+// key updates are skipped wave-uniformly: after the first few thousand rows of a chunk that is almost always.
+// The two best are kept as 32-bit keys (distance << 23 | row offset inside the chunk): taking min / median-of-3 on
+// keys reproduces the reference's strict `<` updates, i.e. the lowest row index wins ties for the best and the
+// second best is the second order statistic of the distances.
 #include "orbx_internal.h"
 
 #include <cmath>
@@ -22,7 +27,7 @@ namespace orbx {
 
 namespace {
 
-constexpr int kQueriesPerBlock = 256;
+constexpr int kWavesPerBlock = 4;            // independent waves; they share the expansion table only
 constexpr int64_t kMaxChunkRows = 1 << 22;   // row offset must fit the 23-bit key field
 constexpr unsigned kEmptyKey = 0xFFFFFFFFu;
 
@@ -31,74 +36,135 @@ struct Partial {       // result of one query over one database chunk
     int64_t idx;       // global row of d1, -1 if none
 };
 
-// v_bcnt_u32_b32 adds its second operand for free; written out so that the eight counts of a pair stay one
-// accumulate chain (left to itself the compiler splits the chain and pays three extra adds per pair).
-__device__ __forceinline__ int bcnt_acc(uint32_t x, int acc) {
-    int r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
-    return r;
-}
-
-__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
-    return max(min(a, b), min(max(a, b), c));
-}
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 }  // namespace
 
-__global__ __launch_bounds__(kQueriesPerBlock) void knn2_kernel(const uint4* __restrict__ query, int64_t nq,
-                                                                const uint4* __restrict__ db, int64_t ndb,
-                                                                int64_t chunkRows, int64_t indexBase,
-                                                                Partial* __restrict__ partial) {
-    const int64_t qi = (int64_t)blockIdx.x * kQueriesPerBlock + threadIdx.x;
-    const int64_t qc = qi < nq ? qi : nq - 1;
-    const uint4 qa = query[2 * qc], qb = query[2 * qc + 1];
+// One wave owns 32 * NQB queries and walks the chunk's rows 32 at a time.
+// Which descriptor bit meets which K position of the matrix instruction is free as long as both operands agree:
+// lane (j, h) of a wave (j = lane % 32: the query of a block / the row of a step; h = lane / 32) supplies, for
+// matrix instruction m, the 32 bits of descriptor dword 4h + m, eight bits to an operand dword through the table.
+template <int NQB>
+__global__ __launch_bounds__(64 * kWavesPerBlock, 2) void knn2_kernel(const uint32_t* __restrict__ query, int64_t nq,
+                                                                       const uint32_t* __restrict__ db, int64_t ndb,
+                                                                       int64_t chunkRows, int64_t indexBase,
+                                                                       Partial* __restrict__ partial) {
+    __shared__ uint32_t lut[256];                  // byte -> eight nibbles, 0b0010 (1.0) where the bit is set
+    {
+        const unsigned t = threadIdx.x;
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v |= ((t >> i) & 1u) << (4 * i + 1);
+        lut[t] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t qtile = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * (32 * NQB);
+    if (qtile >= nq) return;                       // no barrier below: waves are on their own from here
+
+    // ---- this wave's queries as ready B operands: +1.0 = 0b0010, -1.0 = 0b1010 ----
+    uint32_t B[NQB][4][4];
+    int pq[NQB];                                   // |query|
+    unsigned k1[NQB], k2[NQB];
+    float thr[NQB];                                // (distance of k2) - |query|: what the accumulators are compared with
+#pragma unroll
+    for (int b = 0; b < NQB; b++) {
+        const int64_t qi = min(qtile + 32 * b + j, nq - 1);
+        const u32x4* qp = reinterpret_cast<const u32x4*>(query + qi * 8);
+        const u32x4 lo = qp[0], hi = qp[1];
+        pq[b] = __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) +
+                __popc(hi.z) + __popc(hi.w);
+        const u32x4 mine = h ? hi : lo;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) B[b][m][k] = 0x22222222u | (lut[(mine[m] >> (8 * k)) & 255u] << 2);
+        k1[b] = k2[b] = kEmptyKey;
+        thr[b] = (float)((int)(kEmptyKey >> 23) - pq[b]);     // 511 while there is no second best
+    }
+
+    // ---- the chunk's rows ----
     const int64_t j0 = (int64_t)blockIdx.y * chunkRows;
     const int rows = (int)min(chunkRows, ndb - j0);
-    const uint4* __restrict__ base = db + 2 * j0;
-    unsigned k1 = kEmptyKey, k2 = kEmptyKey;
-    // Rows go four at a time. A row can only change the best two if its distance is below the current
-    // second best (its key carries a larger row offset than any key seen before), so the key updates of a
-    // group are skipped when no lane of the wave has such a row: after the first few hundred rows of a chunk
-    // that is almost always, and a pair costs its 16 xor / popcount instructions plus 3/4 of one more.
-    unsigned thr = kEmptyKey >> 23;             // distance of k2 (511 while there is no second best)
-    const int zero = 0;
-    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-    const u32x8* __restrict__ row8 = reinterpret_cast<const u32x8*>(base);   // one s_load_dwordx8 per row
-    auto distance = [&](int r) {
-        const u32x8 w = row8[r];                                             // wave-uniform address
-        int d = bcnt_acc(qa.x ^ w[0], zero);
-        d = bcnt_acc(qa.y ^ w[1], d);
-        d = bcnt_acc(qa.z ^ w[2], d);
-        d = bcnt_acc(qa.w ^ w[3], d);
-        d = bcnt_acc(qb.x ^ w[4], d);
-        d = bcnt_acc(qb.y ^ w[5], d);
-        d = bcnt_acc(qb.z ^ w[6], d);
-        return bcnt_acc(qb.w ^ w[7], d);
-    };
-    auto update = [&](int d, int j) {
-        const unsigned key = ((unsigned)d << 23) | (unsigned)j;
-        k2 = umed3(k1, k2, key);   // k1 <= k2 always holds
-        k1 = min(k1, key);
-    };
-    int j = 0;
-    for (; j + 4 <= rows; j += 4) {
-        int d[4];
+    const int nsteps = (rows + 31) >> 5;
+    // Rows come through a buffer resource over the chunk: a step's address is a scalar offset plus this lane's
+    // constant, and the rows a last, partial step lacks read as zero (their keys are masked below).
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(db + j0 * 8), 0, rows * 32, 0x00027000);
+    const int laneOff = j * 32 + 16 * h;           // the wave reads the step's 1024 bytes as one contiguous piece
+    u32x4 raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff, 0, 0));
+    for (int step = 0; step < nsteps; step++) {
+        uint32_t A[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) d[i] = distance(j + i);
-        const unsigned dmin = (unsigned)min(min(d[0], d[1]), min(d[2], d[3]));
-        if (__builtin_amdgcn_ballot_w64(dmin < thr) != 0) {      // wave-uniform branch
+        for (int m = 0; m < 4; m++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) update(d[i], j + i);
-            thr = k2 >> 23;
+            for (int k = 0; k < 4; k++) A[m][k] = lut[(raw[m] >> (8 * k)) & 255u];
+        if (step + 1 < nsteps)
+            raw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff, (step + 1) * 1024, 0));
+        // accumulator r of this lane is row 8 * (r / 4) + 4 * h + r % 4 of the step
+        const int rowBase = step * 32 + 4 * h;
+#pragma unroll
+        for (int b = 0; b < NQB; b++) {
+            v16f acc = {0};
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const v8i av = {(int)A[m][0], (int)A[m][1], (int)A[m][2], (int)A[m][3], 0, 0, 0, 0};
+                const v8i bv = {(int)B[b][m][0], (int)B[b][m][1], (int)B[b][m][2], (int)B[b][m][3], 0, 0, 0, 0};
+                // format 4 = FP4 for both operands; scale operands that are the constant 0 select the instruction
+                // without block scales (every block scale 1)
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 4, 4, 0, 0, 0, 0);
+            }
+            const float m0 = fminf(fminf(acc[0], acc[1]), acc[2]), m1 = fminf(fminf(acc[3], acc[4]), acc[5]);
+            const float m2 = fminf(fminf(acc[6], acc[7]), acc[8]), m3 = fminf(fminf(acc[9], acc[10]), acc[11]);
+            const float m4 = fminf(fminf(acc[12], acc[13]), acc[14]);
+            const float mn = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), acc[15]));
+            // A row can only change the best two if its distance is below the current second best (a lane meets its
+            // rows in ascending order, so a later row carries a larger key than any key it holds).
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(mn < thr[b]);
+            if (hit == 0) continue;                                  // wave-uniform
+            // key = (acc + |query|) << 23 | row
+            const unsigned base = ((unsigned)pq[b] << 23) + (unsigned)rowBase;
+            if (__popcll(hit) > 6) {               // many lanes have something to take (start of a chunk): no more tests
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int rr = 8 * (r >> 2) + (r & 3);
+                    unsigned key = ((unsigned)(int)acc[r] << 23) + base + (unsigned)rr;
+                    if (rowBase + rr >= rows) key = kEmptyKey;       // past the chunk's end (last step only)
+                    k2[b] = max(k1[b], min(k2[b], key));             // the median of three, given k1 <= k2
+                    k1[b] = min(k1[b], key);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    if (__builtin_amdgcn_ballot_w64(acc[r] < thr[b]) != 0) {
+                        const int rr = 8 * (r >> 2) + (r & 3);
+                        unsigned key = ((unsigned)(int)acc[r] << 23) + base + (unsigned)rr;
+                        if (rowBase + rr >= rows) key = kEmptyKey;
+                        k2[b] = max(k1[b], min(k2[b], key));
+                        k1[b] = min(k1[b], key);
+                    }
+                }
+            }
+            thr[b] = (float)((int)(k2[b] >> 23) - pq[b]);
         }
     }
-    for (; j < rows; j++) update(distance(j), j);
-    if (qi >= nq) return;
-    Partial p;
-    p.d1 = k1 == kEmptyKey ? INT32_MAX : (int32_t)(k1 >> 23);
-    p.d2 = k2 == kEmptyKey ? INT32_MAX : (int32_t)(k2 >> 23);
-    p.idx = k1 == kEmptyKey ? -1 : indexBase + j0 + (int64_t)(k1 & 0x7FFFFFu);
-    partial[(int64_t)blockIdx.y * nq + qi] = p;
+    // ---- lanes j and j + 32 hold the two halves of a query's rows: the best two of the union ----
+#pragma unroll
+    for (int b = 0; b < NQB; b++) {
+        const unsigned o1 = (unsigned)__shfl_xor((int)k1[b], 32), o2 = (unsigned)__shfl_xor((int)k2[b], 32);
+        const unsigned n1 = min(k1[b], o1), n2 = min(max(k1[b], o1), min(k2[b], o2));
+        const int64_t qi = qtile + 32 * b + j;
+        if (h == 0 && qi < nq) {
+            Partial p;
+            p.d1 = n1 == kEmptyKey ? INT32_MAX : (int32_t)(n1 >> 23);
+            p.d2 = n2 == kEmptyKey ? INT32_MAX : (int32_t)(n2 >> 23);
+            p.idx = n1 == kEmptyKey ? -1 : indexBase + j0 + (int64_t)(n1 & 0x7FFFFFu);
+            partial[(int64_t)blockIdx.y * nq + qi] = p;
+        }
+    }
 }
 
 // Folds the per-chunk partials of one query in chunk (= index) order with the reference's update
@@ -576,44 +642,62 @@ __global__ __launch_bounds__(256) void stereo_median_cut_kernel(int cap, const i
 }
 
 namespace {
-inline int64_t pick_chunk_rows(int64_t nq, int64_t ndb) {
-    // enough (query block x chunk) workgroups to fill 256 CUs several times over
-    const int64_t qblocks = (nq + kQueriesPerBlock - 1) / kQueriesPerBlock;
-    int64_t want = (4096 + qblocks - 1) / qblocks;          // chunks wanted
-    if (want < 1) want = 1;
-    int64_t rows = (ndb + want - 1) / want;
-    if (rows < 2048) rows = 2048;                            // keep the fold cheap
-    if (rows > kMaxChunkRows) rows = kMaxChunkRows;
-    // equal chunks: a short last chunk would leave most of the chip idle while the long ones finish
-    const int64_t nchunks = ndb > 0 ? (ndb + rows - 1) / rows : 1;
-    if (ndb > 0) rows = (ndb + nchunks - 1) / nchunks;
-    return rows;
+// How a scan is cut up: query blocks per wave (8, 2 or 1) and rows per chunk.
+// A wave that holds more queries spends less on expanding rows (one expansion serves 32 * nqb queries), but the scan
+// needs about two waves per SIMD to keep the matrix pipe fed, and every chunk starts with a few thousand rows that
+// mostly take the update path, so chunks should be long. Largest nqb first; the first that fills the chip wins.
+struct ScanPlan {
+    int nqb;
+    int64_t rows, nchunks;
+};
+ScanPlan plan_scan(int64_t nq, int64_t ndb) {
+    const int64_t kWavesWanted = 2048, kWavesEnough = 1024;
+    const int nqbs[3] = {8, 2, 1};
+    const int64_t minRows[3] = {65536, 8192, 1024};
+    ScanPlan plan{1, 1, 0};
+    for (int i = 0; i < 3; i++) {
+        const int64_t qwaves = (nq + 32 * nqbs[i] - 1) / (32 * nqbs[i]);
+        int64_t want = (kWavesWanted + qwaves - 1) / qwaves;                // chunks wanted
+        int64_t rows = ndb > 0 ? (ndb + want - 1) / want : 1;
+        rows = std::min(std::max(rows, minRows[i]), kMaxChunkRows);
+        // equal chunks: a short last chunk would leave most of the chip idle while the long ones finish
+        int64_t nchunks = ndb > 0 ? (ndb + rows - 1) / rows : 0;
+        if (ndb > 0) rows = (ndb + nchunks - 1) / nchunks;
+        plan = ScanPlan{nqbs[i], rows, nchunks};
+        if (qwaves * nchunks >= kWavesEnough) break;
+    }
+    return plan;
 }
 }  // namespace
 
 size_t knn2_scratch_bytes(int64_t nq, int64_t ndb) {
     if (nq <= 0) return 0;
-    const int64_t rows = pick_chunk_rows(nq, ndb);
-    const int64_t nchunks = ndb > 0 ? (ndb + rows - 1) / rows : 1;
-    return (size_t)nchunks * (size_t)nq * sizeof(Partial);
+    const ScanPlan plan = plan_scan(nq, ndb);
+    return (size_t)std::max<int64_t>(plan.nchunks, 1) * (size_t)nq * sizeof(Partial);
 }
 
 namespace {
 // The scan over chunks of `rows` database rows into `part`, then the fold in chunk order.
-hipError_t launch_knn2_chunks(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb, int64_t rows,
-                              int64_t nchunks, int32_t init, int64_t indexBase, int64_t* idx, int32_t* d1,
-                              int32_t* d2, void* hits, Partial* part, hipStream_t s) {
-    if (nchunks > 65535) return hipErrorInvalidValue;
-    const unsigned qblocks = (unsigned)((nq + kQueriesPerBlock - 1) / kQueriesPerBlock);
-    if (nchunks > 0) {
-        dim3 grid(qblocks, (unsigned)nchunks, 1), block(kQueriesPerBlock, 1, 1);
-        hipLaunchKernelGGL(knn2_kernel, grid, block, 0, s, reinterpret_cast<const uint4*>(q), nq,
-                           reinterpret_cast<const uint4*>(db), ndb, rows, indexBase, part);
+hipError_t launch_knn2_chunks(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t ndb, const ScanPlan& plan,
+                              int32_t init, int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2, void* hits,
+                              Partial* part, hipStream_t s) {
+    if (plan.nchunks > 65535 || plan.rows > kMaxChunkRows) return hipErrorInvalidValue;
+    if (plan.nchunks > 0) {
+        const int perBlock = 32 * plan.nqb * kWavesPerBlock;
+        dim3 grid((unsigned)((nq + perBlock - 1) / perBlock), (unsigned)plan.nchunks, 1), block(64 * kWavesPerBlock, 1, 1);
+        const uint32_t* q32 = reinterpret_cast<const uint32_t*>(q);
+        const uint32_t* db32 = reinterpret_cast<const uint32_t*>(db);
+        if (plan.nqb == 8)
+            hipLaunchKernelGGL(knn2_kernel<8>, grid, block, 0, s, q32, nq, db32, ndb, plan.rows, indexBase, part);
+        else if (plan.nqb == 2)
+            hipLaunchKernelGGL(knn2_kernel<2>, grid, block, 0, s, q32, nq, db32, ndb, plan.rows, indexBase, part);
+        else
+            hipLaunchKernelGGL(knn2_kernel<1>, grid, block, 0, s, q32, nq, db32, ndb, plan.rows, indexBase, part);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(knn2_fold_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, part,
-                       (int)nchunks, nq, init, idx, d1, d2, static_cast<Partial*>(hits));
+                       (int)plan.nchunks, nq, init, idx, d1, d2, static_cast<Partial*>(hits));
     return hipGetLastError();
 }
 }  // namespace
@@ -626,10 +710,9 @@ hipError_t launch_knn2(const uint8_t* q, int64_t nq, const uint8_t* db, int64_t 
                        int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2, void* hits, void* scratch,
                        size_t scratchBytes, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
-    const int64_t rows = pick_chunk_rows(nq, ndb);
-    const int64_t nchunks = ndb > 0 ? (ndb + rows - 1) / rows : 0;
-    if ((size_t)nchunks * (size_t)nq * sizeof(Partial) > scratchBytes) return hipErrorInvalidValue;
-    return launch_knn2_chunks(q, nq, db, ndb, rows, nchunks, init, indexBase, idx, d1, d2, hits,
+    const ScanPlan plan = plan_scan(nq, ndb);
+    if ((size_t)plan.nchunks * (size_t)nq * sizeof(Partial) > scratchBytes) return hipErrorInvalidValue;
+    return launch_knn2_chunks(q, nq, db, ndb, plan, init, indexBase, idx, d1, d2, hits,
                               static_cast<Partial*>(scratch), s);
 }
 
@@ -647,19 +730,11 @@ namespace {
 std::mutex g_staticMutex;
 Partial* g_staticPartial[kMaxStaticDevices] = {};
 
-// Chunking that keeps nq * nchunks partials inside the fixed array; false when no chunking does.
-bool pick_chunks_bounded(int64_t nq, int64_t ndb, int64_t* rowsOut, int64_t* nchunksOut) {
-    if (nq > kStaticPartials) return false;
-    int64_t rows = pick_chunk_rows(nq, ndb);
-    int64_t nchunks = ndb > 0 ? (ndb + rows - 1) / rows : 0;
-    if (nchunks * nq > kStaticPartials) {
-        nchunks = kStaticPartials / nq;                  // >= 1
-        rows = (ndb + nchunks - 1) / nchunks;
-        if (rows > kMaxChunkRows) return false;          // the row offset must fit its 23-bit key field
-        nchunks = (ndb + rows - 1) / rows;
-    }
-    *rowsOut = rows;
-    *nchunksOut = nchunks;
+// The scan's usual plan, if its nq * nchunks partials fit the fixed array.
+bool plan_scan_static(int64_t nq, int64_t ndb, ScanPlan* out) {
+    const ScanPlan plan = plan_scan(nq, ndb);
+    if (nq > kStaticPartials || plan.nchunks * nq > kStaticPartials) return false;
+    *out = plan;
     return true;
 }
 }  // namespace
@@ -667,8 +742,8 @@ bool pick_chunks_bounded(int64_t nq, int64_t ndb, int64_t* rowsOut, int64_t* nch
 int64_t knn2_static_max_partials() { return kStaticPartials; }
 
 bool knn2_static_fits(int64_t nq, int64_t ndb) {
-    int64_t rows, nchunks;
-    return pick_chunks_bounded(nq, ndb, &rows, &nchunks);
+    ScanPlan plan;
+    return plan_scan_static(nq, ndb, &plan);
 }
 
 // Looks up this device's copy of the array. `device` must be the current device.
@@ -690,8 +765,8 @@ hipError_t launch_knn2_static(int device, const uint8_t* q, int64_t nq, const ui
                               int32_t init, int64_t indexBase, int64_t* idx, int32_t* d1, int32_t* d2,
                               hipStream_t s) {
     if (nq <= 0) return hipSuccess;
-    int64_t rows = 0, nchunks = 0;
-    if (!pick_chunks_bounded(nq, ndb, &rows, &nchunks)) return hipErrorInvalidValue;
+    ScanPlan plan;
+    if (!plan_scan_static(nq, ndb, &plan)) return hipErrorInvalidValue;
     hipError_t e = knn2_static_init(device);
     if (e != hipSuccess) return e;
     Partial* part;
@@ -699,7 +774,7 @@ hipError_t launch_knn2_static(int device, const uint8_t* q, int64_t nq, const ui
         std::lock_guard<std::mutex> lock(g_staticMutex);
         part = g_staticPartial[device];
     }
-    return launch_knn2_chunks(q, nq, db, ndb, rows, nchunks, init, indexBase, idx, d1, d2, nullptr, part, s);
+    return launch_knn2_chunks(q, nq, db, ndb, plan, init, indexBase, idx, d1, d2, nullptr, part, s);
 }
 
 hipError_t launch_knn2_merge(int nparts, int64_t nq, const int64_t* idx, const int32_t* d1,

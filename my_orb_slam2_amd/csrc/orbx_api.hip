@@ -93,6 +93,7 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
     }
     std::vector<uint8_t> blob(std::max<size_t>(bytes, 64));
     HIP_TRY(hipStreamSynchronize(c->stream));   // the old tables may still be in use
+    if (c->lastStream && c->lastStream != c->stream) HIP_TRY(hipStreamSynchronize(c->lastStream));
     if (c->resizeBlob) HIP_TRY(hipFree(c->resizeBlob));
     c->resizeBlob = nullptr;
     HIP_TRY(hipMalloc(&c->resizeBlob, blob.size()));
@@ -352,22 +353,30 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, i
     fs.imgFrameStride = (long long)frame_stride;
     c->fs = fs;
     c->lastFrames = nframes;
-    c->lastStream = s;
     const PyramidGeom& g = c->geom;
     const bool prof = c->profiling;
-    if (prof) HIP_TRY(hipEventRecord(c->ev[0], s));
     // A handful of frames cannot fill the GPU whatever the kernel: what counts then is the length of the chain of
     // dependent launches, so the pyramid comes from the one-launch kernel (more arithmetic, far less waiting).
     // Batches go level by level through the kernel that spends the fewest instructions per pixel.
-    HIP_TRY(launch_pyramid(fs, g, c->resize, nframes, s, nframes <= kFusedMaxFrames ? &c->fused : nullptr));
-    if (prof) HIP_TRY(hipEventRecord(c->ev[1], s));
-    HIP_TRY(launch_fast_cells(fs, g, nframes, c->cfg.ini_th_fast, c->cfg.min_th_fast, s));
-    if (prof) HIP_TRY(hipEventRecord(c->ev[2], s));
-    HIP_TRY(launch_octree(fs, g, nframes, s));
-    if (prof) HIP_TRY(hipEventRecord(c->ev[3], s));
-    HIP_TRY(launch_orient_desc(fs, g, nframes, c->cfg.blur_taps, d_kps, d_desc, cap, d_counts, s));
-    if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
-    HIP_TRY(hipEventRecord(c->evDone, s));
+    auto queue = [&]() -> int {
+        if (prof) HIP_TRY(hipEventRecord(c->ev[0], s));
+        HIP_TRY(launch_pyramid(fs, g, c->resize, nframes, s, nframes <= kFusedMaxFrames ? &c->fused : nullptr));
+        if (prof) HIP_TRY(hipEventRecord(c->ev[1], s));
+        HIP_TRY(launch_fast_cells(fs, g, nframes, c->cfg.ini_th_fast, c->cfg.min_th_fast, s));
+        if (prof) HIP_TRY(hipEventRecord(c->ev[2], s));
+        HIP_TRY(launch_octree(fs, g, nframes, s));
+        if (prof) HIP_TRY(hipEventRecord(c->ev[3], s));
+        HIP_TRY(launch_orient_desc(fs, g, nframes, c->cfg.blur_taps, d_kps, d_desc, cap, d_counts, s));
+        if (prof) HIP_TRY(hipEventRecord(c->ev[4], s));
+        return ORBX_OK;
+    };
+    rc = queue();
+    // Whatever was queued (all of the call, or its first kernels when a launch failed) uses the context's buffers:
+    // the event goes behind it either way, and only then does this stream become "the stream of the last call".
+    const hipError_t recorded = hipEventRecord(c->evDone, s);
+    c->lastStream = s;
+    if (rc) return rc;
+    HIP_TRY(recorded);
     c->haveTimes = prof;
     return ORBX_OK;
 }
@@ -916,32 +925,50 @@ extern "C" int orbx_hamming_knn2(orbx_matcher* m, const uint8_t* query, int64_t 
         return ORBX_ERR_INVALID;
     }
     if (nq == 0) return ORBX_OK;
+    if (ndb > INT32_MAX) {
+        set_error("orbx_hamming_knn2: at most 2^31 - 1 database rows per call");
+        return ORBX_ERR_INVALID;
+    }
     HIP_TRY(hipSetDevice(m->device));
-    uint8_t *dq = nullptr, *ddb = nullptr;
-    int64_t* didx = nullptr;
-    int32_t *dd1 = nullptr, *dd2 = nullptr;
-    int rc = ORBX_OK;
-    auto run = [&]() -> int {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dq), (size_t)nq * 32));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ddb), std::max<size_t>((size_t)ndb * 32, 32)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&didx), (size_t)nq * 8));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dd1), (size_t)nq * 4));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dd2), (size_t)nq * 4));
-        HIP_TRY(hipMemcpyAsync(dq, query, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
-        if (ndb) HIP_TRY(hipMemcpyAsync(ddb, db, (size_t)ndb * 32, hipMemcpyHostToDevice, m->stream));
-        int r = orbx_hamming_knn2_device(m, dq, nq, ddb, ndb, init, 0, didx, dd1, dd2, m->stream);
-        if (r) return r;
-        HIP_TRY(hipMemcpyAsync(idx, didx, (size_t)nq * 8, hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipMemcpyAsync(d1, dd1, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipMemcpyAsync(d2, dd2, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        return ORBX_OK;
-    };
-    rc = run();
-    void* bufs[] = {dq, ddb, didx, dd1, dd2};
-    for (void* p : bufs)
-        if (p) (void)hipFree(p);
-    return rc;
+    hipStream_t s = m->stream;
+    // Inputs, outputs and the scan's partial results share the matcher's one device buffer, which only ever grows;
+    // inputs and outputs of ordinary size go through its pinned staging buffer (one asynchronous copy each way,
+    // pageable copies of the same bytes take several times as long).
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t qBytes = (size_t)nq * 32, dbBytes = (size_t)ndb * 32;
+    const size_t oQ = 0, oDb = oQ + up(qBytes), oIdx = oDb + up(std::max<size_t>(dbBytes, 32)), oD1 = oIdx + up((size_t)nq * 8),
+                 oD2 = oD1 + up((size_t)nq * 4), oPart = oD2 + up((size_t)nq * 4);
+    const size_t partBytes = knn2_scratch_bytes(nq, ndb), total = oPart + partBytes;
+    int rc = matcher_scratch(m, total, s);
+    if (rc) return rc;
+    uint8_t* base = static_cast<uint8_t*>(m->scratch);
+    const size_t inBytes = oIdx, outBytes = oPart - oIdx;
+    const bool staged = inBytes <= ((size_t)64 << 20);
+    if (staged) {
+        if ((rc = matcher_pinned(m, std::max(inBytes, outBytes)))) return rc;
+        std::memcpy(m->pin + oQ, query, qBytes);
+        if (ndb) std::memcpy(m->pin + oDb, db, dbBytes);
+        HIP_TRY(hipMemcpyAsync(base, m->pin, oDb + dbBytes, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(base + oQ, query, qBytes, hipMemcpyHostToDevice, s));
+        if (ndb) HIP_TRY(hipMemcpyAsync(base + oDb, db, dbBytes, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(launch_knn2(base + oQ, nq, base + oDb, ndb, init, 0, reinterpret_cast<int64_t*>(base + oIdx),
+                        reinterpret_cast<int32_t*>(base + oD1), reinterpret_cast<int32_t*>(base + oD2), nullptr,
+                        base + oPart, partBytes, s));
+    if (staged) {
+        HIP_TRY(hipMemcpyAsync(m->pin, base + oIdx, outBytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::memcpy(idx, m->pin, (size_t)nq * 8);
+        std::memcpy(d1, m->pin + (oD1 - oIdx), (size_t)nq * 4);
+        std::memcpy(d2, m->pin + (oD2 - oIdx), (size_t)nq * 4);
+    } else {
+        HIP_TRY(hipMemcpyAsync(idx, base + oIdx, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(d1, base + oD1, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(d2, base + oD2, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return ORBX_OK;
 }
 
 extern "C" int orbx_knn2_merge_device(orbx_matcher* m, int nparts, int64_t nq, const int64_t* d_idx,
@@ -1079,6 +1106,9 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* lef
         HIP_TRY(hipStreamWaitEvent(side[i]->stream, m->evOut, 0));
         if (side[i]->lastStream && side[i]->lastStream != side[i]->stream && side[i]->lastStream != s)
             HIP_TRY(hipStreamWaitEvent(side[i]->lastStream, m->evOut, 0));
+        // A later extraction on any other stream waits for the context's evDone only: it now also stands for
+        // "the stereo kernels have read this context's pyramid" (s has waited for the extraction itself above).
+        HIP_TRY(hipEventRecord(side[i]->evDone, s));
     }
     return ORBX_OK;
 }

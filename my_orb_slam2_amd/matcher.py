@@ -76,7 +76,7 @@ class HammingMatcher:
                                              C.c_void_p(d_db.data_ptr()), d_db.shape[0], int(init),
                                              int(index_base), C.c_void_p(d_idx.data_ptr()),
                                              C.c_void_p(d_d1.data_ptr()), C.c_void_p(d_d2.data_ptr()), sp),
-              "orbx_hamming_knn2_device")
+              "orbx_hamming_knn2_noalloc_device" if noalloc else "orbx_hamming_knn2_device")
         self._hold(stream, d_query, d_db, d_idx, d_d1, d_d2)
 
     def knn2_packed_device(self, d_query, d_db, d_hits, init=256, index_base=0, stream=None):

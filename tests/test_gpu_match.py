@@ -186,6 +186,59 @@ def test_compute_stereo_matches_full(nfeatures, npairs, min_total):
     assert total > min_total
 
 
+def test_stereo_then_extraction_on_another_stream():
+    """A context may be driven from different streams in turn. Extraction on stream X, ComputeStereoMatches on the
+    matcher's stream, then at once an extraction of other frames on stream Y with the same two contexts: the second
+    extraction overwrites the pyramids the SAD refinement reads, so it has to start behind the stereo kernels. The
+    stereo result must equal the one computed with nothing queued behind it."""
+    import torch
+    npairs, nfeatures = 16, 1200
+    ex_l = m.ORBextractor(nfeatures, 1.2, 8, 20, 7, max_batch=npairs)
+    ex_r = m.ORBextractor(nfeatures, 1.2, 8, 20, 7, max_batch=npairs)
+    cap = ex_l.capacity
+    left = np.stack([m.synth_frame(300 + p) for p in range(npairs)])
+    right = np.stack([m.synth_frame(300 + p, right_view=True) for p in range(npairs)])
+    rng = np.random.default_rng(7)
+    other = rng.integers(0, 256, left.shape, dtype=np.uint8)
+    d_left, d_right, d_other = (torch.from_numpy(a).cuda() for a in (left, right, other))
+
+    def alloc():
+        return (torch.zeros((npairs, cap, 7), dtype=torch.float32, device="cuda"),
+                torch.zeros((npairs, cap, 32), dtype=torch.uint8, device="cuda"),
+                torch.zeros(npairs, dtype=torch.int32, device="cuda"))
+    bf, b = 47.90639384423901, 47.90639384423901 / 435.2046959714599
+    hm = m.HammingMatcher()
+    sx, sy = torch.cuda.Stream(), torch.cuda.Stream()
+    results = []
+    for overlapped in (False, True):
+        kl, dl, nl = alloc()
+        kr, dr, nr = alloc()
+        k2, d2, n2 = alloc()
+        k3, d3, n3 = alloc()
+        ur = torch.full((npairs, cap), -7.0, dtype=torch.float32, device="cuda")
+        z = torch.full((npairs, cap), -7.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ex_l.extract_batch_device(d_left, kl, dl, nl, stream=sx.cuda_stream)
+        ex_r.extract_batch_device(d_right, kr, dr, nr, stream=sx.cuda_stream)
+        hm.compute_stereo_matches_device(ex_l, ex_r, kl, dl, nl, kr, dr, nr, bf, b, ur, z)
+        if overlapped:
+            ex_l.extract_batch_device(d_other, k2, d2, n2, stream=sy.cuda_stream)
+            ex_r.extract_batch_device(d_other, k3, d3, n3, stream=sy.cuda_stream)
+        hm.synchronize()
+        torch.cuda.synchronize()
+        results.append((ur.cpu().numpy(), z.cpu().numpy(), nl.cpu().numpy()))
+    (ur0, z0, n0), (ur1, z1, n1) = results
+    assert np.array_equal(n0, n1)
+    assert np.array_equal(ur0, ur1) and np.array_equal(z0, z1)
+    assert int((ur0 >= 0).sum()) > 50 * npairs
+    # and the serial result is the oracle's
+    ol, orr = orc.Extractor(nfeatures), orc.Extractor(nfeatures)
+    okl, odl = ol.extract(left[0])
+    okr, odr = orr.extract(right[0])
+    our, oz, _ = orc.compute_stereo_matches(ol, orr, okl, odl, okr, odr, bf, b)
+    assert np.array_equal(ur0[0, :n0[0]], our) and np.array_equal(z0[0, :n0[0]], oz)
+
+
 @pytest.mark.parametrize("nshards", [1, 2, 3, 8])
 def test_packed_scan_and_merge_of_simulated_ranks(nshards):
     """The sharded-database path without a process group: every "rank" scans its contiguous shard into packed

@@ -28,7 +28,7 @@ def test_noalloc_matches_allocating_entry_point_twice():
     hm = m.HammingMatcher(0)
     g = torch.Generator(device="cuda").manual_seed(7)
     # (nq, ndb): the first call uses many chunks of the fixed array, the second (smaller) call leaves most of
-    # what the first wrote in place; then a bounded-chunking case (nq * default chunks exceeds the array) and
+    # what the first wrote in place; then many queries over a short database (one chunk, 300000 partials) and
     # tiny / degenerate shapes.
     cases = [(5000, 300000), (1237, 70001), (300000, 40000), (1, 1), (3, 0), (257, 2), (64, 5000)]
     for k, (nq, ndb) in enumerate(cases):
@@ -76,4 +76,13 @@ def test_noalloc_refuses_oversized_problem():
     hm.knn2_device(q, db, idx, d1, d2)
     hm.synchronize()
     assert int((d1 != 0).sum()) == 0 and int((idx != 0).sum()) == 0
+    # fewer queries than the array has entries, but a database of three chunks: 3 * nq partials do not fit either
+    nq = 1_000_000
+    db = torch.zeros((9_000_000, 32), dtype=torch.uint8, device="cuda")
+    idx.fill_(-7)
+    with pytest.raises(OrbxError) as ei:
+        hm.knn2_device(q[:nq], db, idx[:nq], d1[:nq], d2[:nq], noalloc=True)
+    assert ei.value.code == -3
+    torch.cuda.synchronize()
+    assert int((idx != -7).sum()) == 0
     hm.close()

@@ -10,7 +10,7 @@ for path in sys.argv[1:]:
         name = row["Kernel_Name"].split("(")[0][-40:]
         acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name, counters in sorted(acc.items()):
-    if "orbx" not in name:
+    if "orbx" not in name and "probe" not in name and "knn2" not in name:
         continue
     n = max(len(v) for v in counters.values())
     print("%-42s dispatches=%d" % (name, n))
