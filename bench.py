@@ -16,8 +16,12 @@ the library's launch stream; `cpu_baseline` times the CPU oracle (a port of the 
 reference itself needs OpenCV 4 and cannot be built here) on the host cores.  The other BASELINE configs ride
 along as extra keys of the same line, each timed the same way (barrier + device synchronisation either side,
 maximum over ranks): `hd1080` (configs[3], frame-parallel), `stereo` (configs[2], pair-parallel, extraction x2 +
-the whole of Frame::ComputeStereoMatches) and `hamming` (configs[4]: 1 M queries against a 100 M row database
-split over the ranks, ONE all-gather of 16 bytes per query and rank, exact fold, ratio test).
+the whole of Frame::ComputeStereoMatches), `hamming` (configs[4]: 1 M queries against a 100 M row database
+split over the ranks, ONE all-gather of 16 bytes per query and rank, exact fold, ratio test) and `host_fed` (the
+headline workload with frames starting and results ending in pinned host memory, three batches in flight: the
+PCIe-inclusive figure, never what `value` reports).
+The timed region of the headline is at least one second long: the K steps of `--steps` are repeated in whole
+rounds until it is (`rounds_timed`), and `ms_per_step` is the mean over all of them.
 """
 import argparse
 import json
@@ -39,13 +43,27 @@ BYTES_PER_FRAME = 1117367 + 756407 + 60000
 # The same split by stage: what each kernel has to move at the very least.
 LEVEL_PX = 1117367
 DERIVED_PX = 756407
-STAGE_BYTES = {
-    "pyramid": (LEVEL_PX - 210 * 134) + DERIVED_PX,     # read levels 0..6, write levels 1..7
-    "fast_cells": LEVEL_PX,                             # read every level once (+ a few KB of candidates)
-    "octree": 4 * 10000 + 4 * 1000,                     # ~10k packed candidates in, ~1k selected out
-    "orient_desc": 1000 * (43 * 43 + 60),               # one 43x43 patch per keypoint + its outputs
-}
-LEGS = ("hd1080", "stereo", "hamming")
+
+
+def stage_bytes(level_px, derived_px, last_level_px, nkp):
+    """What each kernel has to move at the very least, per frame."""
+    return {
+        "pyramid": (level_px - last_level_px) + derived_px,     # read levels 0..6, write levels 1..7
+        "fast_cells": level_px,                                 # read every level once (+ a few KB of candidates)
+        "octree": 4 * 10 * nkp + 4 * nkp,                       # ~10 packed candidates per keypoint in, the selected out
+        "orient_desc": nkp * (43 * 43 + 60),                    # one 43x43 patch per keypoint + its outputs
+    }
+
+
+STAGE_BYTES = stage_bytes(LEVEL_PX, DERIVED_PX, 210 * 134, 1000)
+# configs[3]: 1920x1080 levels sum to 6,419,321 px, derived levels to 4,345,721, last level 536x301, 2000 keypoints
+STAGE_BYTES_HD = stage_bytes(6419321, 4345721, 536 * 301, 2000)
+BYTES_PER_FRAME_HD = 6419321 + 4345721 + 120000
+STAGE_BYTES_STEREO = stage_bytes(LEVEL_PX, DERIVED_PX, 210 * 134, 1200)
+PCIE_PEAK_GBS = 63.0           # PCIe Gen5 x16 (spec)
+# FP4 matrix peak (dense): 1024 SIMDs x one 32x32x64 instruction (65,536 multiply-adds) per 32 cycles x 2.4 GHz
+MFMA_FP4_PEAK_TFLOPS = 1024 * 2 * 65536 / 32 * 2.4e9 / 1e12
+LEGS = ("hd1080", "stereo", "hamming", "host_fed")
 
 
 def parse():
@@ -59,7 +77,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--legs", default=",".join(LEGS),
-                    help="comma-separated extra workloads out of hd1080,stereo,hamming ('' = none)")
+                    help="comma-separated extra workloads out of hd1080,stereo,hamming,host_fed ('' = none)")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="shortest timed region of the headline: the K steps are repeated in whole rounds until it is reached")
     ap.add_argument("--no-hamming", action="store_true", help="same as leaving hamming out of --legs")
     ap.add_argument("--knn-nq", type=int, default=1_000_000)
     ap.add_argument("--knn-ndb", type=int, default=100_000_000)
@@ -211,16 +231,40 @@ class Rank:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(self, fn, steps, warmup):
-        """warmup untimed steps, then exactly `steps` steps between two fences; maximum over ranks, in seconds."""
+    def timed(self, fn, steps, warmup, min_seconds=0.0):
+        """warmup untimed steps, then exactly `steps` steps between two fences; maximum over ranks, in seconds.
+        With min_seconds the `steps` steps are repeated in whole rounds (every rank the same number, taken from
+        the slowest rank's first round) until the timed region is that long; returns (seconds, rounds)."""
         for i in range(warmup):
             fn(i)
+        rounds = 1
+        if min_seconds > 0:
+            self.fence()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                fn(i)
+            self.fence()
+            first = self.max_over_ranks(time.perf_counter() - t0)
+            rounds = max(1, int(min_seconds / max(first, 1e-6) + 0.999))
         self.fence()
         t0 = time.perf_counter()
-        for i in range(steps):
+        for i in range(steps * rounds):
             fn(i)
         self.fence()
-        return self.max_over_ranks(time.perf_counter() - t0)
+        self.last_own_seconds = time.perf_counter() - t0
+        dt = self.max_over_ranks(self.last_own_seconds)
+        return (dt, rounds) if min_seconds > 0 else dt
+
+    def gather_own_seconds(self):
+        """Every rank's own time for the last timed region (rank order), for the per-rank figures."""
+        import torch
+        import torch.distributed as dist
+        if not self.use_dist:
+            return [self.last_own_seconds]
+        t = torch.tensor([self.last_own_seconds], dtype=torch.float64, device="cuda" if self.a.backend == "nccl" else "cpu")
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return [float(x.item()) for x in out]
 
 
 class ExtractLeg:
@@ -248,6 +292,68 @@ class ExtractLeg:
 
     def mean_keypoints(self):
         return float(self.outs[0][2].float().mean().item())
+
+    def stage_ms(self, reps=9, overlapped=False):
+        """Median per-stage kernel time of a launch of context 0 (HIP events on the library's launch stream).
+        alone: nothing else runs beside it. overlapped: the launch sits inside the rotation over all contexts, as in
+        the timed region (the other contexts' launches are queued before and after it)."""
+        ex = self.exs[0]
+        ex.set_profiling(True)
+        samples = {}
+        for i in range(reps):
+            if overlapped and self.nctx > 1:
+                for c in range(1, self.nctx):
+                    self.launch(self.nctx * (2 * i) + c)
+                self.launch(self.nctx * (2 * i + 1))                     # context 0, profiled
+                for c in range(1, self.nctx):
+                    self.launch(self.nctx * (2 * i + 1) + c)
+            else:
+                self.launch(self.nctx * i)
+            for k, v in ex.stage_ms().items():
+                samples.setdefault(k, []).append(v)
+        ex.set_profiling(False)
+        # the median of the launches: one launch that meets a clock change or a preemption must not name the dominant kernel
+        return {k: sorted(v)[len(v) // 2] for k, v in samples.items()}
+
+
+def hbm_roofline(stage, per_frame_bytes, frames):
+    """roofline object for the stage that takes longest: its algorithmic bytes per launch over its kernel time."""
+    dom = max(stage, key=stage.get)
+    nbytes = per_frame_bytes[dom] * frames
+    achieved = nbytes / (stage[dom] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": nbytes,
+            "kernel_ms": round(stage[dom], 4), "stage_ms": {k: round(v, 4) for k, v in stage.items()}}
+
+
+class HostFedLeg:
+    """The headline workload fed from the host: frames start and results end in pinned host memory, three slots
+    (an extractor context and a stream each) queue copy in -> orbx_extract_batch_device -> copy out, so the
+    transfers of one batch overlap the kernels of another. PCIe included; never what `value` reports."""
+
+    def __init__(self, main, slots=3):
+        import torch
+        self.B, self.slots = main.B, min(slots, len(main.exs))
+        self.exs = main.exs[:self.slots]
+        cap = self.exs[0].capacity
+        self.streams = [torch.cuda.Stream() for _ in range(self.slots)]
+        self.h_in = [torch.from_numpy(main.host[:self.B]).clone().pin_memory() for _ in range(self.slots)]
+        self.d_in = [torch.empty((self.B, H, W), dtype=torch.uint8, device="cuda") for _ in range(self.slots)]
+        self.d_out = main.outs[:self.slots]
+        self.h_out = [tuple(torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in self.d_out[0]) for _ in range(self.slots)]
+        self.bytes_in = int(self.h_in[0].numel())
+        self.bytes_out = int(sum(t.numel() * t.element_size() for t in self.h_out[0]))
+
+    def submit(self, i):
+        import torch
+        k = i % self.slots
+        st = self.streams[k]
+        st.synchronize()                                 # the slot's previous batch is back in host memory
+        with torch.cuda.stream(st):
+            self.d_in[k].copy_(self.h_in[k], non_blocking=True)
+            self.exs[k].extract_batch_device(self.d_in[k], *self.d_out[k], stream=st.cuda_stream)
+            for h, d in zip(self.h_out[k], self.d_out[k]):
+                h.copy_(d, non_blocking=True)
 
 
 class StereoLeg:
@@ -284,6 +390,30 @@ class StereoLeg:
     def finish(self):
         for s in self.sets:
             s["hm"].synchronize()
+
+    def stage_ms(self, reps=5):
+        """Median kernel times of one step, each part alone: the left extraction's four stages (the right one is the
+        same work) and the kernels of ComputeStereoMatches (band search, SAD refinement, median cut) between two
+        events on the matcher's stream."""
+        import torch
+        s = self.sets[0]
+        s["exl"].set_profiling(True)
+        samples = {}
+        for _ in range(reps):
+            s["exl"].extract_batch_device(self.left, *s["L"])
+            s["exr"].extract_batch_device(self.right, *s["R"])
+            for k, v in s["exl"].stage_ms().items():
+                samples.setdefault(k, []).append(v)
+            torch.cuda.synchronize()
+            st = s["hm"]._own_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            s["hm"].compute_stereo_matches_device(s["exl"], s["exr"], *s["L"], *s["R"], self.bf, self.b, s["ur"], s["z"])
+            e1.record(st)
+            s["hm"].synchronize()
+            samples.setdefault("stereo_matches", []).append(e0.elapsed_time(e1))
+        s["exl"].set_profiling(False)
+        return {k: sorted(v)[len(v) // 2] for k, v in samples.items()}
 
 
 def hamming_leg(R, a):
@@ -337,14 +467,20 @@ def hamming_leg(R, a):
     if bad:
         raise SystemExit("bench.py: kNN property checks failed: %s" % json.dumps(st))
     pairs = nq * ndb / dt
-    # VALU bound: 8 v_xor + 8 v_bcnt per pair. A wave64 VALU instruction occupies its SIMD for 4 cycles (measured:
-    # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.0), i.e. 64 lanes/clk/CU: 256 CUs x 64 lanes x 2.4 GHz per GPU.
-    peak = R.world * 256 * 64 * 2.4e9 / 16
+    # Matrix-pipe bound: a pair is a 256-term dot product of FP4 operands (v_mfma_f32_32x32x64_f8f6f4, four per
+    # 32 x 32 tile of pairs), 512 flop per pair against the dense FP4 peak; the xor + popcount form it replaced was
+    # bound by VALU issue at 256 CUs x 64 lanes x 2.4 GHz / 16 = 2.46e12 pairs/s.
+    tflops = pairs * 512 / 1e12
+    peak = R.world * MFMA_FP4_PEAK_TFLOPS
     out = {"metric": "Hamming pairs/s (top-2 kNN + ratio test, %d x %d, database sharded over %d GPU%s)"
                      % (nq, ndb, R.world, "" if R.world == 1 else "s"),
            "value": pairs, "seconds": round(dt, 3), "n_gpus": R.world, "scaling": "strong",
            "rows_per_gpu": hi - lo, "collective": "one all_gather of nq x 16 B per rank" if R.world > 1 else "none",
-           "valu_peak_pairs_per_s": peak, "frac_of_valu_peak": round(pairs / peak, 4), "checks": st}
+           "roofline": {"bound": "mfma", "kernel": "knn2_kernel", "achieved": round(tflops, 1), "peak": round(peak, 1),
+                        "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": None, "dtype": "fp4 (exact: bits as 0 / +-1)",
+                        "flop_per_pair": 512, "time": "whole leg (scan + fold + ratio test), wall clock"},
+           "valu_form_peak_pairs_per_s": R.world * 256 * 64 * 2.4e9 / 16,
+           "checks": st}
     if R.rank == 0 and R.world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = hamming_cpu_baseline(q[:4096].cpu().numpy(), db[: 1 << 20].cpu().numpy())
     return out
@@ -403,7 +539,7 @@ def run_rank(a):
     R.init_group()
     ranks_in_group = dist.get_world_size() if R.use_dist else 1
 
-    # ---- headline: exactly a.steps steps of a.launches batched launches each ----
+    # ---- headline: a.steps steps of a.launches batched launches each, in whole rounds until >= a.min_seconds ----
     L = a.launches
 
     def step(i):
@@ -411,42 +547,64 @@ def run_rank(a):
             main.launch(i * L + j)
     for i in range(max(8, 2 * nctx)):                   # clocks and caches up before anything is counted
         main.launch(i)
-    dt = R.timed(step, a.steps, a.warmup)
+    dt, rounds = R.timed(step, a.steps, a.warmup, a.min_seconds)
+    steps_timed = a.steps * rounds
+    own_seconds = R.gather_own_seconds()
     kp_mean = main.mean_keypoints()
 
-    # ---- per-stage kernel time, HIP events on the library's launch stream (outside the timed region) ----
-    ex = main.exs[0]
-    ex.set_profiling(True)
-    samples = {}
-    reps = 9
-    for i in range(reps):
-        main.launch(nctx * i)               # context 0 only, so stages do not overlap another launch
-        for k, v in ex.stage_ms().items():
-            samples.setdefault(k, []).append(v)
-    ex.set_profiling(False)
-    # the median of the launches: one launch that meets a clock change or a preemption must not name the dominant kernel
-    acc = {k: sorted(v)[len(v) // 2] for k, v in samples.items()}
+    # ---- per-stage kernel time, HIP events on the library's launch stream (outside the timed region):
+    # context 0 alone, and context 0 inside the rotation over all contexts as in the timed region ----
+    acc = main.stage_ms(9, overlapped=False)
+    acc_overlapped = main.stage_ms(9, overlapped=True)
 
     extra = {}
+    if "host_fed" in legs:
+        hf = HostFedLeg(main)
+        for i in range(hf.slots):
+            hf.submit(i)
+        fsteps = 48
+        fdt = R.timed(hf.submit, fsteps, 3)
+        frames_s = R.world * hf.B * fsteps / fdt
+        extra["host_fed"] = {"workload": "configs[1] with frames starting and results ending in pinned host memory: %d slots, "
+                                         "each copy in -> orbx_extract_batch_device -> copy out on its own stream" % hf.slots,
+                             "value": round(frames_s, 1), "unit": "frames/s", "n_gpus": R.world, "frames_per_launch_per_gpu": hf.B,
+                             "launches": fsteps, "scaling": "weak", "ms_per_launch": round(fdt / fsteps * 1e3, 3),
+                             "bytes_per_launch": {"in": hf.bytes_in, "out": hf.bytes_out},
+                             "h2d_gb_s_per_gpu": round(hf.bytes_in * fsteps / fdt / 1e9, 2),
+                             "d2h_gb_s_per_gpu": round(hf.bytes_out * fsteps / fdt / 1e9, 2),
+                             "pcie_peak_gb_s": PCIE_PEAK_GBS,
+                             "h2d_frac_of_pcie": round(hf.bytes_in * fsteps / fdt / 1e9 / PCIE_PEAK_GBS, 4),
+                             "bound": "the host link, not the kernels"}
+        del hf
     if hd is not None:
         hsteps = 48
         hdt = R.timed(hd.launch, hsteps, 6)
+        hd_fps = R.world * hd.B * hsteps / hdt
+        hd_stage = hd.stage_ms(5)
         extra["hd1080"] = {"workload": "configs[3]: synthetic 1920x1080 frames, nFeatures 2000, 8 levels, frame-parallel",
-                           "value": round(R.world * hd.B * hsteps / hdt, 1), "unit": "frames/s", "n_gpus": R.world,
+                           "value": round(hd_fps, 1), "unit": "frames/s", "n_gpus": R.world,
                            "frames_per_launch_per_gpu": hd.B, "launches": hsteps, "scaling": "weak",
                            "ms_per_launch": round(hdt / hsteps * 1e3, 3), "collective": "none",
-                           "mean_keypoints_per_frame": round(hd.mean_keypoints(), 1)}
+                           "mean_keypoints_per_frame": round(hd.mean_keypoints(), 1),
+                           "roofline": dict(hbm_roofline(hd_stage, STAGE_BYTES_HD, hd.B),
+                                            path_bytes_per_frame=BYTES_PER_FRAME_HD,
+                                            path_frac=round(BYTES_PER_FRAME_HD * hd_fps / R.world / 1e9 / HBM_PEAK_GBS, 5))}
     if stereo is not None:
         ssteps = 48
         sdt = R.timed(stereo.step, ssteps, 6)
         stereo.finish()
         matched = float((stereo.sets[0]["ur"] >= 0).sum().item()) / stereo.B
+        st_stage = stereo.stage_ms()
+        st_bytes = dict(STAGE_BYTES_STEREO, stereo_matches=2 * 1200 * 60 + 1200 * 2 * 11 * 21)   # both sides' keypoints + descriptors, the SAD windows
         extra["stereo"] = {"workload": "configs[2]: stereo pairs 752x480, nFeatures 1200, left + right extraction + "
                                        "Frame::ComputeStereoMatches, pair p on rank p mod G",
                            "value": round(R.world * stereo.B * ssteps / sdt, 1), "unit": "stereo pairs/s",
                            "n_gpus": R.world, "pairs_per_launch_per_gpu": stereo.B, "launches": ssteps,
                            "scaling": "weak", "ms_per_launch": round(sdt / ssteps * 1e3, 3), "collective": "none",
-                           "mean_stereo_matches_per_pair": round(matched, 1)}
+                           "mean_stereo_matches_per_pair": round(matched, 1),
+                           "roofline": dict(hbm_roofline(st_stage, st_bytes, stereo.B),
+                                            note="stage times of ONE side's extraction (the other side repeats them) and of "
+                                                 "the ComputeStereoMatches kernels, each alone")}
     host64 = main.host[:64]
     del main, hd, stereo
     torch.cuda.empty_cache()
@@ -459,7 +617,7 @@ def run_rank(a):
         return
     world = R.world
     frames_per_step = B * L
-    fps = world * frames_per_step * a.steps / dt
+    fps = world * frames_per_step * steps_timed / dt
     dom = max(acc, key=acc.get)
     dom_bytes = STAGE_BYTES[dom] * B
     achieved = dom_bytes / (acc[dom] * 1e-3) / 1e9
@@ -475,7 +633,8 @@ def run_rank(a):
     out = {
         "metric": "ORB frames/s (752x480, 8 lvl, 1000 kp)",
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / steps_timed * 1e3, 4), "steps_timed": steps_timed, "rounds_timed": rounds,
+        "timed_seconds": round(dt, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "configs[1]: synthetic batch of 4096 752x480 uint8 frames, ORB extract+describe, "
                                "nFeatures=1000, 8 levels, scale 1.2, FAST 20/7",
@@ -491,6 +650,10 @@ def run_rank(a):
                      "kernel_ms": round(acc[dom], 4),
                      "valu_issue": valu,
                      "stage_ms": {k: round(v, 4) for k, v in acc.items()},
+                     "stage_ms_overlapped": {k: round(v, 4) for k, v in acc_overlapped.items()},
+                     "stage_ms_note": "stage_ms: a launch of one context with nothing beside it (kernel_ms and achieved "
+                                      "use it); stage_ms_overlapped: the same launch inside the rotation over all "
+                                      "contexts, as in the timed region",
                      "path_bytes_per_frame": BYTES_PER_FRAME,
                      "path_achieved": round(BYTES_PER_FRAME * fps / world / 1e9, 2),
                      "path_frac": round(BYTES_PER_FRAME * fps / world / 1e9 / HBM_PEAK_GBS, 5)},
@@ -504,7 +667,14 @@ def run_rank(a):
                                 "peak": round(issue_peak / 1e9, 2), "unit": "G wave64-instructions/s",
                                 "frac": round(issue_rate / issue_peak, 4),
                                 "frac_of_kernel_cycles": valu["valu_issue_frac"],
+                                "valu_cycles_per_inst": 4,
+                                "valu_cycles_per_inst_source": "probe: tools/probe/valu_issue_probe.hip, "
+                                                               "profiles/r01_valu_issue_probe.txt (4.0-4.4 cycles per wave64 "
+                                                               "instruction per SIMD at 8 waves per SIMD, every class used here); "
+                                                               "SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.008 quad-cycles agrees",
                                 "instruction_count_source": pmc_source}
+    if world > 1:
+        out["per_rank_value"] = [round(frames_per_step * steps_timed / t, 1) for t in own_seconds]
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, host64)
         out["gpu_over_cpu_all_cores"] = round(fps / out["cpu_baseline"]["value"], 1)
