@@ -15,6 +15,8 @@
 //      score (cv cornerScore) is S - 1; corners keep their S in an LDS score map;
 //   4. corners that beat their 8 neighbours strictly are written in row-major order to the cell's
 //      slot array.
+#include <cstdlib>
+
 #include "orbx_internal.h"
 
 namespace orbx {
@@ -39,8 +41,9 @@ __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) 
 // With d_k = v - c_k: max over arcs of min(d) = v - min over arcs of max(c), and min over arcs of max(d) =
 // v - max over arcs of min(c), so the sixteen differences are never formed; and an arc's maximum of c is 255 minus
 // its minimum of 255 - c, so one network of minima over the pairs (c, 255 - c), one pair per dword, serves both
-// polarities: an arc of nine is three windows of three (one three-input instruction per window and per arc), and
-// the sixteen arc values fold three at a time into (largest arc minimum, 255 - smallest arc maximum).
+// polarities. The arcs k..k+8 and k+1..k+9 (k even) share the eight positions k+1..k+8, and
+// max(min(core, c_k), min(core, c_k+9)) = min(core, max(c_k, c_k+9)): eight pair minima, eight such maxima, two
+// three-input minima per even k and four three-input maxima give (largest arc minimum, 255 - smallest arc maximum).
 template <int pitch>
 __device__ __forceinline__ int corner_strength(const uint8_t* p) {
     const int v = p[0];
@@ -66,15 +69,16 @@ __device__ __forceinline__ int corner_strength(const uint8_t* p) {
     uint32_t w[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(w[k]) : "v"(c[k]), "s"(kSpread), "v"(kHalves));
-    uint32_t m3[16], m9[16];
+    uint32_t pr[8], ends[8], r[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) m3[k] = pk_min3(w[k], w[(k + 1) & 15], w[(k + 2) & 15]);
+    for (int i = 0; i < 8; i++) {
+        pr[i] = pk_min3(w[2 * i + 1], w[(2 * i + 2) & 15], w[(2 * i + 2) & 15]);     // positions 2i+1, 2i+2
+        ends[i] = pk_max3(w[2 * i], w[(2 * i + 9) & 15], w[(2 * i + 9) & 15]);       // the two ends around core 2i
+    }
 #pragma unroll
-    for (int k = 0; k < 16; k++) m9[k] = pk_min3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
-    uint32_t best = m9[15];
-#pragma unroll
-    for (int k = 0; k < 14; k += 2) best = pk_max3(best, m9[k], m9[k + 1]);
-    best = pk_max3(best, m9[14], m9[14]);
+    for (int i = 0; i < 8; i++)
+        r[i] = pk_min3(pk_min3(pr[i], pr[(i + 1) & 7], pr[(i + 2) & 7]), pr[(i + 3) & 7], ends[i]);
+    const uint32_t best = pk_max3(pk_max3(r[0], r[1], r[2]), pk_max3(r[3], r[4], r[5]), pk_max3(r[6], r[7], r[7]));
     const int loMax = (int)(best & 0xFFFFu) - 0x6400;          // largest arc minimum
     const int hiMin = 255 + 0x6400 - (int)(best >> 16);        // smallest arc maximum
     return max(v - hiMin, loMax - v);      // darker-arc strength, brighter-arc strength
@@ -124,7 +128,7 @@ __device__ __forceinline__ int prefix_count(unsigned long long m) {
 // PITCH is the LDS row pitch of the staged cell (bytes, multiple of 4); a compile-time constant so that
 // all sixteen circle offsets fold into the ds_read immediate offsets.
 constexpr int kTileRowBatch = 40;    // tile rows staged per round of loads; the tile area is a multiple of it
-constexpr int kCellsPerBlock = 4;   // waves per workgroup; every wave works alone on its own cell and LDS slice
+constexpr int kDefaultCellsPerBlock = 4;   // waves per workgroup; every wave works alone on its own cell and LDS slice
 
 // Orders a wave's own LDS traffic: the hardware runs one wave's DS instructions in order, so only the
 // compiler has to be kept from moving accesses across this point.
@@ -133,7 +137,7 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int PITCH>
+template <int PITCH, int kCellsPerBlock>
 __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSet fs, PyramidGeom g, int iniTh,
                                                                           int minTh, int ldsPerWave) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
@@ -176,7 +180,6 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
 
     // ---- 1. stage the cell in LDS ----
     uint8_t* tile = smem;
-    constexpr int pitch = PITCH;
     // Tile column c holds image column iniX - 1 + c, so the first scanned pixel (iniX + 3) sits at tile column 4
     // and groups of four scanned pixels are whole LDS dwords.
     constexpr int xo = 1;
@@ -217,13 +220,15 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
             }
         }
     }
-    uint8_t* score = smem + g.maxTileBytes;            // (sw+2) x (sh+2), zero ring
+    // Score map: sh + 2 rows of the tile's own pitch with a zero ring, so that a pixel's offset e = y * PITCH + x
+    // (scan coordinates) addresses the tile (+ 3 * PITCH + 4) and the map (+ PITCH + 1) alike, and a queue entry
+    // is that offset.
+    uint8_t* score = smem + g.maxTileBytes;
     uint16_t* queue = reinterpret_cast<uint16_t*>(score + g.maxScoreBytes);
-    const int sp = sw + 2;
     {
         // 16 bytes per lane and store; the last store may run a few bytes into the queue, which is filled later
         uint4* s128 = reinterpret_cast<uint4*>(score);
-        const int n16 = (sp * (sh + 2) + 15) >> 4;
+        const int n16 = ((sh + 2) * PITCH + 15) >> 4;
         for (int i = lane; i < n16; i += 64) s128[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     wave_sync();
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     // A lane tests four horizontally adjacent pixels per step from five LDS dwords (the row itself: the group,
     // its left and right neighbours; rows -3 and +3: the group), every byte picked by an SDWA operand select.
     // 8 lanes span a scan of up to 32 px (8 rows per step), 16 lanes a wider one (4 rows per step).
-    // A queue entry is (y << 8) | x.
+    // A queue entry is y * PITCH + x.
     const bool narrow = sw <= 32;                      // cells are < 60 px wide (width / floor(width / 30))
     const int rowsPerIter = narrow ? 8 : 4;
     const int gx = narrow ? lane & 7 : lane & 15, ly = narrow ? lane >> 3 : lane >> 4;
@@ -256,8 +261,8 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
             tLo[odd] = ((uint32_t)tcur * 0x01000100u) | in0 | in1;
             tHi[odd] = tLo[odd] | 0x00FF00FFu;
         }
-        int yx = (ly << 8) | (4 * gx);
-        const int yxEnd = sh << 8;
+        int e0 = ly * PITCH + 4 * gx;
+        const int eEnd = sh * PITCH;
         const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile) + (ly + 3) * P4 + gx;
         for (int y0 = 0; y0 < sh; y0 += rowsPerIter) {
             const uint32_t A = t32[0], B = t32[1], C = t32[2], U = t32[1 - 3 * P4], D = t32[1 + 3 * P4];
@@ -288,23 +293,25 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
                 m[odd + 2] = cmp_lt_word1(mnmax[odd], lo[odd]) | cmp_lt_word1(hi[odd], mxmin[odd]);
             }
             if (y0 + rowsPerIter > sh) {               // last step: lanes on rows below the scan drop out
-                const unsigned long long ym = __builtin_amdgcn_ballot_w64(yx < yxEnd);
+                const unsigned long long ym = __builtin_amdgcn_ballot_w64(e0 < eEnd);
 #pragma unroll
                 for (int j = 0; j < 4; j++) m[j] &= ym;
             }
-            // row-major rank: everything queued by lower lanes, then this lane's own earlier pixels
-            int pos = nq;
+            // row-major rank: everything queued by lower lanes, then this lane's own earlier pixels (what earlier
+            // steps queued is a scalar and goes into the base address)
+            int pos = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[j], pos));
+            uint16_t* qdst = queue + nq;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const bool pass = __builtin_amdgcn_inverse_ballot_w64(m[j]);
-                if (pass) queue[pos] = (uint16_t)(yx + j);
+                if (pass) qdst[pos] = (uint16_t)(e0 + j);
                 if (j < 3) pos = add_mask_bit(pos, m[j]);          // pos += pass
                 nq += __popcll(m[j]);
             }
-            yx += rowsPerIter << 8;
+            e0 += rowsPerIter * PITCH;
             t32 += rowsPerIter * P4;
         }
     }
@@ -314,16 +321,15 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     int nc = 0;
     for (int base = 0; base < nq; base += 64) {
         const int qi = base + lane;
-        int yx = 0, S = 0;
+        int e = 0, S = 0;
         if (qi < nq) {
-            yx = queue[qi];
-            const int y = yx >> 8, x = yx & 255;
-            S = corner_strength<PITCH>(tile + (y + 3) * pitch + xo + x + 3);
-            if (S > tcur) score[(y + 1) * sp + x + 1] = (uint8_t)S; else S = 0;
+            e = queue[qi];
+            S = corner_strength<PITCH>(tile + 3 * PITCH + xo + 3 + e);
+            if (S > tcur) score[PITCH + 1 + e] = (uint8_t)S; else S = 0;
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(S > 0);
         // in-place compaction: position nc+prefix <= qi, and every lane has read queue[qi] above
-        if (S > 0) queue[nc + prefix_count(m)] = (uint16_t)yx;
+        if (S > 0) queue[nc + prefix_count(m)] = (uint16_t)e;
         nc += __popcll(m);
     }
     wave_sync();
@@ -332,12 +338,11 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     for (int base = 0; base < nc; base += 64) {
         const int qi = base + lane;
         bool keep = false;
-        int x = 0, y = 0, sc = 0;
+        int e = 0, sc = 0;
         if (qi < nc) {
-            const int yx = queue[qi];
-            y = yx >> 8;
-            x = yx & 255;
-            const uint8_t* s = score + (y + 1) * sp + x + 1;
+            e = queue[qi];
+            constexpr int sp = PITCH;
+            const uint8_t* s = score + PITCH + 1 + e;
             sc = s[0] - 1;                           // every queued pixel is a corner at this threshold
             const int a0 = s[-sp - 1], a1 = s[-sp], a2 = s[-sp + 1], a3 = s[-1], a4 = s[1], a5 = s[sp - 1], a6 = s[sp],
                       a7 = s[sp + 1];
@@ -348,6 +353,10 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
             const int pos = nout + prefix_count(m);
+            // e = y * PITCH + x with e < 2^13: the quotient by a 20-bit reciprocal is exact (the error of the rounded-up
+            // reciprocal, e * 2^-20, stays far below 1 / PITCH)
+            constexpr int kRecip = ((1 << 20) + PITCH - 1) / PITCH;
+            const int y = (int)(__umul24((uint32_t)e, (uint32_t)kRecip) >> 20), x = e - y * PITCH;
             // FAST reports sub-image coordinates (x+3, y+3); the caller adds j*wCell, i*hCell (:814-815)
             if (pos < L.slotCap) slotOut[pos] = pack_cand(cj * L.wCell + x + 3, ci * L.hCell + y + 3, sc);
         }
@@ -362,12 +371,14 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
 hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nframes, int iniTh, int minTh,
                              hipStream_t s) {
     if (g.totalCells == 0) return hipSuccess;
+    static const int wavesEnv = getenv("ORBX_FAST_WAVES") ? atoi(getenv("ORBX_FAST_WAVES")) : 0;
+    const int waves = wavesEnv == 1 || wavesEnv == 2 ? wavesEnv : kDefaultCellsPerBlock;
     const int ldsPerWave = (g.maxTileBytes + g.maxScoreBytes + 2 * g.maxScanPix + 16 + 15) & ~15;
-    const size_t lds = (size_t)ldsPerWave * kCellsPerBlock;
-    dim3 grid(nframes, (g.totalCells + kCellsPerBlock - 1) / kCellsPerBlock, 1), block(64 * kCellsPerBlock, 1, 1);
+    const size_t lds = (size_t)ldsPerWave * waves;
+    dim3 grid(nframes, (g.totalCells + waves - 1) / waves, 1), block(64 * waves, 1, 1);
     // level 0 is read with dword loads like the other levels: the caller of this launcher has made it 4-byte aligned
     if ((uintptr_t)fs.img % 4 || fs.imgRowStride % 4 || fs.imgFrameStride % 4) return hipErrorInvalidValue;
-    const bool small = g.tilePitch == 48;
+    const int tp = g.tilePitch;
     // the widest possible cells (59 x 59 px at pitch 80) need a little over the default 64 KB of dynamic LDS
     auto launch = [&](auto kernel) -> hipError_t {
         if (lds > 64 * 1024) {
@@ -378,7 +389,9 @@ hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nfram
         hipLaunchKernelGGL(kernel, grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
         return hipGetLastError();
     };
-    return small ? launch(fast_cells_kernel<48>) : launch(fast_cells_kernel<80>);
+    if (waves == 1) return tp == 40 ? launch(fast_cells_kernel<40, 1>) : tp == 48 ? launch(fast_cells_kernel<48, 1>) : launch(fast_cells_kernel<80, 1>);
+    if (waves == 2) return tp == 40 ? launch(fast_cells_kernel<40, 2>) : tp == 48 ? launch(fast_cells_kernel<48, 2>) : launch(fast_cells_kernel<80, 2>);
+    return tp == 40 ? launch(fast_cells_kernel<40, 4>) : tp == 48 ? launch(fast_cells_kernel<48, 4>) : launch(fast_cells_kernel<80, 4>);
 }
 
 }  // namespace orbx

@@ -49,7 +49,7 @@ struct PyramidGeom {
     int totalSel;           // per frame
     long long pyrBytes;     // per frame, levels >= 1
     int nodeCap;            // quadtree node table capacity
-    int tilePitch;          // LDS row pitch of a staged FAST cell: 48 or 80 bytes
+    int tilePitch;          // LDS row pitch of a staged FAST cell: 40, 48 or 80 bytes
     int maxTileBytes;       // LDS bytes of the largest FAST cell tile
     int maxScanPix;         // most scanned pixels in one cell
     int maxScoreBytes;      // LDS bytes of the largest cell score map

@@ -124,21 +124,25 @@ bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g,
             maxWCell = std::max(maxWCell, L.wCell);
             maxHCell = std::max(maxHCell, L.hCell);
             g.maxScanPix = std::max(g.maxScanPix, L.wCell * L.hCell);
-            g.maxScoreBytes = std::max(g.maxScoreBytes, align_up((L.wCell + 2) * (L.hCell + 2), 4));
         }
         if (L.w > 4096 + 2 * kBorder || L.h > 4096 + 2 * kBorder) {
             err = "image larger than 4096 px per side";
             return false;
         }
     }
-    // A staged cell row holds up to 3 bytes of alignment slack + the cell + 6 px, rounded up to
-    // dwords; every level of a launch uses the same pitch: 48 bytes when all cells fit, else 80.
-    g.tilePitch = ((3 + maxWCell + 6 + 3) & ~3) <= 48 ? 48 : 80;
+    // A staged cell row holds one byte of alignment slack + the cell + 6 px, rounded up to dwords; every level of a
+    // launch uses the same pitch: 40 bytes when all cells fit (cells up to 33 px wide: the usual 30-32 px cells),
+    // else 48, else 80. The smaller the pitch, the more workgroups share a CU's LDS.
+    {
+        const int rowBytes = (1 + maxWCell + 6 + 3) & ~3;
+        g.tilePitch = rowBytes <= 40 ? 40 : ((3 + maxWCell + 6 + 3) & ~3) <= 48 ? 48 : 80;
+    }
     if (maxWCell > 64 || maxHCell > 64) {   // cannot happen: a cell is width / floor(width / 30) < 60 px
         err = "FAST cell larger than 64 px";
         return false;
     }
     g.maxTileBytes = g.tilePitch * ((maxHCell + 6 + 39) / 40 * 40);   // fast_cells stages rows in batches of 40
+    g.maxScoreBytes = align_up(g.tilePitch * (maxHCell + 2), 16);      // the score map has the tile's pitch
     g.nodeCap = (g.nodeCap + 3) & ~3;         // the quadtree reads node keys four at a time
     g.totalCells = cells;
     g.totalSlots = slots;

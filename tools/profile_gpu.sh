@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --steps 10 --warmup 1 --launches 1 --unique 256 --contexts 1 --no-cpu-baseline --legs="
+ARGS="$ROOT/bench.py --steps 10 --warmup 1 --launches 1 --unique 256 --contexts 1 --no-cpu-baseline --min-seconds 0 --legs="
 cd /tmp
 timeout -k 10 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 $ARGS > "$OUT/stats_bench.json"
 pmc() {
@@ -16,6 +16,7 @@ pmc() {
 }
 pmc sq1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU
 pmc sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_WAIT_INST_LDS
+pmc sq3 SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc grbm GRBM_GUI_ACTIVE
