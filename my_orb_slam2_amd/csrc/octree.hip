@@ -25,7 +25,9 @@ namespace orbx {
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreadsBatch = 256;   // workgroup size in batched calls: many (frame, level) workgroups share the chip
+constexpr int kThreadsFew = 1024;    // calls of a few frames: the chip is nearly empty and a level's passes over its
+                                     // candidates are dependent memory round trips, so more threads = fewer trips each
 constexpr int kBatch = 4;          // candidates a thread loads before it uses the first (hides the memory latency)
 
 // Inclusive scan over the 64 lanes of a wave with DPP adds (no LDS traffic): shifts by 1, 2, 4, 8 inside each row of
@@ -44,6 +46,7 @@ __device__ __forceinline__ int wave_scan_inclusive(int x) {
 // Inclusive scan of data[0..n) in place. `part` holds kThreads ints. All threads must call.
 // Each thread owns a run of ceil(n / 256) elements (one element in all but the largest quotas); run totals are
 // scanned inside each wave and the four wave totals are combined through LDS: two barriers in all.
+template <int kThreads>
 __device__ void block_scan_inclusive(int* data, int n, int* part) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int per = (n + kThreads - 1) / kThreads;
@@ -66,6 +69,7 @@ __device__ void block_scan_inclusive(int* data, int n, int* part) {
 // holds more than one point (it is split; cc holds its four child counts) and 0 otherwise. data[i] receives the
 // inclusive sums: low half = split nodes up to and including i, high half = the (children - 1) of those. Both stay
 // below 2^16 (the node table has fewer than 2^14 entries). Two barriers; *zeroed is cleared between them.
+template <int kThreads>
 __device__ void sweep_scan(const int* cnt, const int* cc, int* data, int n, int* part, int* zeroed) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int per = (n + kThreads - 1) / kThreads;
@@ -112,6 +116,7 @@ __device__ __forceinline__ int quadrant(uint32_t c, const Nodes& nd, int n) {
 }
 
 // The whole selection for one level, with the level's candidates at `cand` and their node indices at `nid`.
+template <int kThreads>
 __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom& L, int nodeCap,
                            uint8_t* lds, uint32_t* selOut, int32_t* selCountOut) {
     const int t = threadIdx.x;
@@ -159,7 +164,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
     // drop empty roots, keep order
     for (int i = t; i < nIni; i += kThreads) keptPos[i] = B.cnt[i] > 0 ? 1 : 0;
     __syncthreads();
-    block_scan_inclusive(keptPos, nIni, part);
+    block_scan_inclusive<kThreads>(keptPos, nIni, part);
     int Lc = nIni ? keptPos[nIni - 1] : 0;
     for (int i = t; i < nIni; i += kThreads) {
         if (B.cnt[i] > 0) {
@@ -227,7 +232,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
             // ---- a sweep: every node with more than one point is split, in list order, so one scan over the nodes
             // gives every split node its rank and the creation index of its first child, and every other node the
             // number of unsplit nodes before it ----
-            sweep_scan(cur.cnt, cc, rank, Lc, part, &sh[2]);
+            sweep_scan<kThreads>(cur.cnt, cc, rank, Lc, part, &sh[2]);
             const int tot = Lc ? rank[Lc - 1] : 0;
             const int m = tot & 0xFFFF;
             C = (tot >> 16) + m;                         // children created this round
@@ -302,7 +307,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
             sinc[r] = (c4[0] > 0) + (c4[1] > 0) + (c4[2] > 0) + (c4[3] > 0) - 1;
         }
         __syncthreads();
-        block_scan_inclusive(sinc, m, part);
+        block_scan_inclusive<kThreads>(sinc, m, part);
         if (t == 0) sh[0] = m;
         __syncthreads();
         for (int r = t; r < m; r += kThreads)
@@ -319,7 +324,7 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
         // ---- new node table ----
         for (int i = t; i < Lc; i += kThreads) keptPos[i] = (cur.cnt[i] > 1 && rank[i] < nsplit) ? 0 : 1;
         __syncthreads();
-        block_scan_inclusive(keptPos, Lc, part);
+        block_scan_inclusive<kThreads>(keptPos, Lc, part);
         if (t == 0) sh[2] = 0;
         __syncthreads();
         for (int i = t; i < Lc; i += kThreads) {
@@ -389,11 +394,16 @@ __device__ void distribute(uint32_t* cand, uint16_t* nid, int P, const LevelGeom
 
 }  // namespace
 
-size_t octree_lds_bytes(const PyramidGeom& g) {
+namespace {
+size_t lds_bytes(const PyramidGeom& g, int threads) {
     // 12 shorts + 14 ints per node, scan scratch, scalars
-    return (size_t)g.nodeCap * (12 * 2 + 14 * 4) + (kThreads + 8) * 4 + 16;
+    return (size_t)g.nodeCap * (12 * 2 + 14 * 4) + (threads + 8) * 4 + 16;
 }
+}  // namespace
 
+size_t octree_lds_bytes(const PyramidGeom& g) { return lds_bytes(g, kThreadsFew); }
+
+template <int kThreads>
 __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGeom g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // This kernel waits far more than it computes; when its waves share a SIMD with the compute-bound kernels of
@@ -479,19 +489,24 @@ __global__ __launch_bounds__(kThreads) void octree_kernel(FrameSet fs, PyramidGe
         }
     }
     __syncthreads();
-    distribute(cand, nid, P, L, g.nodeCap, smem, selOut, selCountOut);
+    distribute<kThreads>(cand, nid, P, L, g.nodeCap, smem, selOut, selCountOut);
 }
 
 hipError_t launch_octree(const FrameSet& fs, const PyramidGeom& g, int nframes, hipStream_t s) {
-    dim3 grid(nframes, g.nlevels, 1), block(kThreads, 1, 1);
-    const size_t lds = octree_lds_bytes(g);
-    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it for this kernel
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(octree_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(octree_kernel, grid, block, lds, s, fs, g);
-    return hipGetLastError();
+    const bool few = nframes <= 8;
+    const int threads = few ? kThreadsFew : kThreadsBatch;
+    dim3 grid(nframes, g.nlevels, 1), block(threads, 1, 1);
+    const size_t lds = lds_bytes(g, threads);
+    auto launch = [&](auto kernel) -> hipError_t {
+        if (lds > 64 * 1024) {   // above the default dynamic-LDS limit: raise it for this kernel
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, fs, g);
+        return hipGetLastError();
+    };
+    return few ? launch(octree_kernel<kThreadsFew>) : launch(octree_kernel<kThreadsBatch>);
 }
 
 }  // namespace orbx

@@ -3,10 +3,13 @@
 // match.hip. There is no CPU fallback: without a usable HIP device every compute entry point
 // returns ORBX_ERR_HIP.
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "orbx_internal.h"
 
@@ -21,6 +24,35 @@ using namespace orbx;
             return ORBX_ERR_HIP;                                                        \
         }                                                                               \
     } while (0)
+
+// Stream ordering. Several streams work on one context's buffers (the caller's streams in turn, the matcher's
+// stream during stereo matching) and are ordered by events only, never by the host. The rule every path here obeys:
+// a hipStreamWaitEvent names an event whose hipEventRecord THIS host thread has already submitted. Waits then depend
+// only on work submitted earlier, so the dependencies form no cycle, and on a device that multiplexes many streams
+// over a few hardware queues (four per process here) a wait packet can never sit in front of the record it waits
+// for. (An arrangement that queued one stream's whole chain, waits included, before the other stream's records
+// did hang on this box.) OrderedEvent keeps the "has been recorded" fact and wait_event() refuses a wait that
+// would break the rule instead of queuing it.
+struct OrderedEvent {
+    hipEvent_t ev = nullptr;
+    unsigned long long recorded = 0;      // sequence number of the last record, 0 = never
+};
+namespace {
+std::atomic<unsigned long long> g_eventSeq{0};   // contexts may be driven from different host threads (one each)
+hipError_t record_event(OrderedEvent& e, hipStream_t s) {
+    hipError_t r = hipEventRecord(e.ev, s);
+    if (r == hipSuccess) e.recorded = ++g_eventSeq;
+    return r;
+}
+int wait_event(hipStream_t s, const OrderedEvent& e, const char* what) {
+    if (!e.recorded) {
+        set_error("stream order: wait for '%s' before any record of it was submitted", what);
+        return ORBX_ERR_STATE;
+    }
+    HIP_TRY(hipStreamWaitEvent(s, e.ev, 0));
+    return ORBX_OK;
+}
+}  // namespace
 
 struct orbx_ctx {
     orbx_config cfg;
@@ -54,8 +86,25 @@ struct orbx_ctx {
     hipEvent_t ev[ORBX_NUM_STAGES + 1] = {};
     // recorded behind every batched call: a later call on another stream waits for it before it reuses the
     // context's buffers
-    hipEvent_t evDone = nullptr;
+    OrderedEvent evDone;
+    // Host-buffer calls of a few frames replay their chain (copy in, four kernels, copy out) as one HIP graph per
+    // (size, frame count, capacity); every address in it belongs to the context's own staging buffers. Dropped
+    // whenever a buffer or table the kernels were given is reallocated.
+    struct Replay {
+        int w, h, n, cap;
+        hipGraphExec_t exec;
+    };
+    std::vector<Replay> replays;
+    bool capturing = false;      // the batched entry point is being recorded into a graph: no events of its own
+    int useGraph = -1;           // ORBX_GRAPH=0 switches the replay path off (-1: not read yet)
 };
+
+namespace {
+void drop_replays(orbx_ctx* c) {
+    for (auto& r : c->replays) (void)hipGraphExecDestroy(r.exec);
+    c->replays.clear();
+}
+}  // namespace
 
 namespace {
 
@@ -94,6 +143,7 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
     std::vector<uint8_t> blob(std::max<size_t>(bytes, 64));
     HIP_TRY(hipStreamSynchronize(c->stream));   // the old tables may still be in use
     if (c->lastStream && c->lastStream != c->stream) HIP_TRY(hipStreamSynchronize(c->lastStream));
+    drop_replays(c);                            // recorded launches carry the old tables' addresses
     if (c->resizeBlob) HIP_TRY(hipFree(c->resizeBlob));
     c->resizeBlob = nullptr;
     HIP_TRY(hipMalloc(&c->resizeBlob, blob.size()));
@@ -225,7 +275,7 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_ctx** out) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(he));
         return fail(ORBX_ERR_HIP);
     }
-    he = hipEventCreateWithFlags(&c->evDone, hipEventDisableTiming);
+    he = hipEventCreateWithFlags(&c->evDone.ev, hipEventDisableTiming);
     if (he != hipSuccess) {
         set_error("hipEventCreate failed: %s", hipGetErrorString(he));
         return fail(ORBX_ERR_HIP);
@@ -245,6 +295,7 @@ extern "C" int orbx_create(const orbx_config* cfg, orbx_ctx** out) {
 extern "C" void orbx_destroy(orbx_ctx* c) {
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_replays(c);
     void* bufs[] = {c->fs.pyr, c->fs.cellCount, c->fs.slots, c->fs.cand, c->fs.nid, c->fs.sel,
                     c->fs.selCount, c->resizeBlob, c->fusedBlob, c->stageImg, c->stageOut};
     for (void* p : bufs)
@@ -253,7 +304,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (c->pinIn) (void)hipHostFree(c->pinIn);
     for (hipEvent_t e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    if (c->evDone) (void)hipEventDestroy(c->evDone);
+    if (c->evDone.ev) (void)hipEventDestroy(c->evDone.ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -334,7 +385,7 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, i
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     // The context's buffers (pyramid, candidates, selection, staging) are shared by all its calls: work queued on
     // another stream than the previous call's starts only after that call has finished with them.
-    if (c->lastStream && c->lastStream != s) HIP_TRY(hipStreamWaitEvent(s, c->evDone, 0));
+    if (!c->capturing && c->lastStream && c->lastStream != s && (rc = wait_event(s, c->evDone, "context done"))) return rc;
     FrameSet fs = c->fs;
     if (nframes == 1) frame_stride = 0;                 // never used to address anything
     if ((uintptr_t)d_images % 4 || row_stride % 4 || frame_stride % 4) {
@@ -354,7 +405,7 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, i
     c->fs = fs;
     c->lastFrames = nframes;
     const PyramidGeom& g = c->geom;
-    const bool prof = c->profiling;
+    const bool prof = c->profiling && !c->capturing;
     // A handful of frames cannot fill the GPU whatever the kernel: what counts then is the length of the chain of
     // dependent launches, so the pyramid comes from the one-launch kernel (more arithmetic, far less waiting).
     // Batches go level by level through the kernel that spends the fewest instructions per pixel.
@@ -371,9 +422,10 @@ extern "C" int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_images, i
         return ORBX_OK;
     };
     rc = queue();
+    if (c->capturing) return rc;                // the caller records the event behind the replayed graph
     // Whatever was queued (all of the call, or its first kernels when a launch failed) uses the context's buffers:
     // the event goes behind it either way, and only then does this stream become "the stream of the last call".
-    const hipError_t recorded = hipEventRecord(c->evDone, s);
+    const hipError_t recorded = record_event(c->evDone, s);
     c->lastStream = s;
     if (rc) return rc;
     HIP_TRY(recorded);
@@ -400,6 +452,7 @@ int ensure_staging(orbx_ctx* c, int cap) {
     if (rc) return rc;
     if (cap > c->stageCap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
+        drop_replays(c);
         if (c->stageOut) HIP_TRY(hipFree(c->stageOut));
         c->stageOut = nullptr;
         if (c->pinOut) HIP_TRY(hipHostFree(c->pinOut));
@@ -450,6 +503,57 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, const uint8_t* images, int nframe
                     for (int y = 0; y < height; y++) std::memcpy(dst + y * pitch, src + y * row_stride, (size_t)width);
                 }
             }
+        }
+        if (c->useGraph < 0) {
+            const char* e = getenv("ORBX_GRAPH");
+            c->useGraph = e && e[0] == '0' ? 0 : 1;
+        }
+        if (c->useGraph == 1 && nframes <= kFusedMaxFrames && !c->profiling &&
+            (!c->lastStream || c->lastStream == c->stream)) {
+            const OutLayout lay((size_t)nframes, (size_t)cap);
+            if ((rc = ensure_geometry(c, width, height))) return rc;       // tables are made outside the recording
+            hipGraphExec_t exec = nullptr;
+            for (auto& r : c->replays)
+                if (r.w == width && r.h == height && r.n == nframes && r.cap == cap) exec = r.exec;
+            if (!exec) {
+                hipGraph_t graph = nullptr;
+                HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+                c->capturing = true;
+                hipError_t e1 = hipMemcpyAsync(c->stageImg, c->pinIn, fstride * (size_t)nframes, hipMemcpyHostToDevice, c->stream);
+                int r1 = orbx_extract_batch_device(c, c->stageImg, nframes, width, height, pitch, fstride,
+                                                   reinterpret_cast<orbx_keypoint*>(c->stageOut + lay.kps),
+                                                   c->stageOut + lay.desc, cap, reinterpret_cast<int32_t*>(c->stageOut),
+                                                   c->stream);
+                hipError_t e2 = hipMemcpyAsync(c->pinOut, c->stageOut, lay.total, hipMemcpyDeviceToHost, c->stream);
+                c->capturing = false;
+                hipError_t e3 = hipStreamEndCapture(c->stream, &graph);
+                if (r1) { if (graph) (void)hipGraphDestroy(graph); return r1; }
+                HIP_TRY(e1);
+                HIP_TRY(e2);
+                HIP_TRY(e3);
+                hipError_t e4 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                HIP_TRY(e4);
+                if (c->replays.size() >= 4) {
+                    (void)hipGraphExecDestroy(c->replays.front().exec);
+                    c->replays.erase(c->replays.begin());
+                }
+                c->replays.push_back(orbx_ctx::Replay{width, height, nframes, cap, exec});
+            }
+            HIP_TRY(hipGraphLaunch(exec, c->stream));
+            c->lastStream = c->stream;
+            HIP_TRY(record_event(c->evDone, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const int32_t* hc = reinterpret_cast<const int32_t*>(c->pinOut);
+            for (int f = 0; f < nframes; f++) {
+                counts[f] = hc[f];
+                const size_t n = (size_t)std::min(std::max(hc[f], 0), cap);
+                std::memcpy(kps + (size_t)f * cap, c->pinOut + lay.kps + (size_t)f * cap * sizeof(orbx_keypoint),
+                            n * sizeof(orbx_keypoint));
+                std::memcpy(desc + (size_t)f * cap * ORBX_DESC_BYTES, c->pinOut + lay.desc + (size_t)f * cap * ORBX_DESC_BYTES,
+                            n * ORBX_DESC_BYTES);
+            }
+            return ORBX_OK;
         }
         HIP_TRY(hipMemcpyAsync(c->stageImg, c->pinIn, fstride * (size_t)nframes, hipMemcpyHostToDevice, c->stream));
     } else if (row_stride == pitch && frame_stride == fstride) {
@@ -759,8 +863,8 @@ struct orbx_matcher {
     float* scale = nullptr;   // device copy of scale factors [0..15] and inverse scale factors [16..31]
     float hostScale[2 * ORBX_MAX_LEVELS] = {0};   // what `scale` holds
     bool scaleValid = false;
-    hipEvent_t evIn[2] = {nullptr, nullptr};      // "the extractor contexts' work is done"
-    hipEvent_t evOut = nullptr;                   // "the matcher has read the contexts' pyramids"
+    OrderedEvent evIn[2];                         // "the extractor contexts' work is done"
+    OrderedEvent evOut;                           // "the matcher has read the contexts' pyramids"
     std::vector<BowRow> bowRows;                  // kept between calls of the vocabulary-node search for their storage
     BowReplayScratch bowTmp;
     std::vector<WindowQuery> winQueries;          // the same for the initialization search
@@ -806,8 +910,8 @@ extern "C" int orbx_matcher_create(int device, orbx_matcher** out) {
     m->device = device;
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->scale), sizeof(float) * 2 * ORBX_MAX_LEVELS);
-    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&m->evIn[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->evOut, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&m->evIn[i].ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->evOut.ev, hipEventDisableTiming);
     if (e == hipSuccess) e = knn2_static_init(device);   // address of this device's fixed partial-result array
     if (e != hipSuccess) {
         set_error("orbx_matcher_create: %s", hipGetErrorString(e));
@@ -824,7 +928,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher* m) {
     if (m->scratch) (void)hipFree(m->scratch);
     if (m->pin) (void)hipHostFree(m->pin);
     if (m->scale) (void)hipFree(m->scale);
-    for (hipEvent_t ev : {m->evIn[0], m->evIn[1], m->evOut})
+    for (hipEvent_t ev : {m->evIn[0].ev, m->evIn[1].ev, m->evOut.ev})
         if (ev) (void)hipEventDestroy(ev);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -1068,8 +1172,8 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* lef
     orbx_ctx* side[2] = {left, right};
     for (int i = 0; i < 2; i++)
         if (side[i]->lastStream && side[i]->lastStream != s) {
-            HIP_TRY(hipEventRecord(m->evIn[i], side[i]->lastStream));
-            HIP_TRY(hipStreamWaitEvent(s, m->evIn[i], 0));
+            HIP_TRY(record_event(m->evIn[i], side[i]->lastStream));
+            if (int wrc = wait_event(s, m->evIn[i], "extraction done")) return wrc;
         }
     const size_t n = (size_t)npairs * cap;
     const size_t bandBytes = (stereo_band_scratch_bytes(npairs, cap) + 255) / 256 * 256;
@@ -1101,14 +1205,14 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_matcher* m, orbx_ctx* lef
     pyramid_view(right, rv);
     HIP_TRY(launch_stereo_refine(npairs, cap, lv, rv, d_kl, d_nl, d_kr, bestIdx, bestDist, m->scale,
                                  m->scale + ORBX_MAX_LEVELS, bf, maxD, d_uright, d_depth, sad, m->scratch, s));
-    HIP_TRY(hipEventRecord(m->evOut, s));
+    HIP_TRY(record_event(m->evOut, s));
     for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipStreamWaitEvent(side[i]->stream, m->evOut, 0));
+        if (int wrc = wait_event(side[i]->stream, m->evOut, "pyramids read")) return wrc;
         if (side[i]->lastStream && side[i]->lastStream != side[i]->stream && side[i]->lastStream != s)
-            HIP_TRY(hipStreamWaitEvent(side[i]->lastStream, m->evOut, 0));
+            if (int wrc = wait_event(side[i]->lastStream, m->evOut, "pyramids read")) return wrc;
         // A later extraction on any other stream waits for the context's evDone only: it now also stands for
         // "the stereo kernels have read this context's pyramid" (s has waited for the extraction itself above).
-        HIP_TRY(hipEventRecord(side[i]->evDone, s));
+        HIP_TRY(record_event(side[i]->evDone, s));
     }
     return ORBX_OK;
 }

@@ -63,12 +63,14 @@ public:
 
     // operator()(image, mask, keypoints, descriptors) on plain memory; mask is ignored as in the
     // reference. descriptors receives keypoints.size() rows of 32 bytes. An empty image leaves both
-    // outputs untouched (src/ORBextractor.cc:1038-1039). fetchPyramid fills mvImagePyramid (stereo
-    // matching reads it, src/Frame.cc:510,600-617); mono callers can skip that copy.
+    // outputs untouched (src/ORBextractor.cc:1038-1039). fetchPyramid fills mvImagePyramid at once (stereo
+    // matching on the host reads it, src/Frame.cc:510,600-617); without it the eight levels stay on the device
+    // until ImagePyramid() is called, which mono frames (src/Frame.cc:214-240) never do.
     void operator()(const uint8_t* image, int cols, int rows, size_t step,
                     std::vector<orbx_keypoint>& keypoints, std::vector<uint8_t>& descriptors,
                     bool fetchPyramid = false) {
         if (!image || cols <= 0 || rows <= 0) return;
+        pyramidFresh_ = false;
         keypoints.resize(cap_);
         descriptors.resize(static_cast<size_t>(cap_) * ORBX_DESC_BYTES);
         int n = 0;
@@ -76,7 +78,18 @@ public:
         if (rc != ORBX_OK) throw std::runtime_error(std::string("orbx_extract: ") + orbx_last_error());
         keypoints.resize(n);
         descriptors.resize(static_cast<size_t>(n) * ORBX_DESC_BYTES);
-        if (fetchPyramid) FetchPyramid();
+        if (fetchPyramid || fetchAlways_) FetchPyramid();
+    }
+
+    // Stereo on the host (the reference's own Frame::ComputeStereoMatches) reads mvImagePyramid after every call:
+    // SetFetchPyramid(true) on both extractors of a stereo system restores that behaviour for both overloads.
+    // Callers of orbx_compute_stereo_matches_device never need the levels on the host.
+    void SetFetchPyramid(bool always) { fetchAlways_ = always; }
+
+    // mvImagePyramid of the last call, copied from the device on first use.
+    const std::vector<PyramidLevel>& ImagePyramid() {
+        if (!pyramidFresh_) FetchPyramid();
+        return mvImagePyramid;
     }
 
 #ifdef ORBX_WITH_OPENCV
@@ -88,7 +101,7 @@ public:
         CV_Assert(image.type() == CV_8UC1);
         std::vector<orbx_keypoint> k;
         std::vector<uint8_t> d;
-        (*this)(image.data, image.cols, image.rows, image.step, k, d, true);
+        (*this)(image.data, image.cols, image.rows, image.step, k, d, false);   // levels on demand: ImagePyramid()
         _keypoints.resize(k.size());
         if (!k.empty()) std::memcpy(static_cast<void*>(_keypoints.data()), k.data(), k.size() * sizeof(orbx_keypoint));
         if (k.empty()) { _descriptors.release(); return; }
@@ -106,6 +119,7 @@ public:
             if (orbx_get_level(ctx_, 0, l, 1, p.data.data(), p.step) != ORBX_OK)
                 throw std::runtime_error(std::string("orbx_get_level: ") + orbx_last_error());
         }
+        pyramidFresh_ = true;
     }
 
     int GetLevels() { return orbx_get_levels(ctx_); }
@@ -126,6 +140,7 @@ private:
     }
     orbx_ctx* ctx_ = nullptr;
     int nlevels_ = 0, cap_ = 0;
+    bool fetchAlways_ = false, pyramidFresh_ = false;
 };
 
 // ORBmatcher::DescriptorDistance on two 32-byte descriptor rows (src/ORBmatcher.cc:1698-1714).
@@ -165,11 +180,14 @@ inline void WriteDescriptors(std::ostream& f, const std::vector<uint8_t>& desc) 
     f.write(reinterpret_cast<const char*>(header), sizeof(header));
     f.write(reinterpret_cast<const char*>(desc.data()), static_cast<std::streamsize>(desc.size()));
 }
-// Returns false (and leaves desc empty) on a short read or a header that is not rows x 32 of CV_8UC1.
+// Returns false (and leaves desc empty) on a short read or a header that is not rows x 32 of CV_8UC1. An empty
+// matrix is written as {0, 0, 0} by the reference (a released cv::Mat has no columns either) and reads back as no
+// descriptors.
 inline bool ReadDescriptors(std::istream& f, std::vector<uint8_t>& desc) {
     desc.clear();
     uint32_t header[3] = {0, 0, 0};
     f.read(reinterpret_cast<char*>(header), sizeof(header));
+    if (f.good() && header[0] == 0u && header[2] == 0u) return true;
     if (!f.good() || header[1] != ORBX_DESC_BYTES || header[2] != 0u ||
         header[0] > StreamBytesLeft(f) / ORBX_DESC_BYTES)
         return false;

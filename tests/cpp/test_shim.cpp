@@ -50,6 +50,30 @@ int main() {
         std::stringstream s4(good.substr(0, good.size() - 1));
         if (!ORB_SLAM2::ReadKeyPoints(s4, kb) || ORB_SLAM2::ReadDescriptors(s4, db)) return 6;
     }
+    {
+        // a keyframe without keypoints: the reference writes an empty cv::Mat as {0, 0, 0}; it must read back as
+        // "no descriptors", and so must {0, 32, 0}
+        const uint32_t empties[2][3] = {{0u, 0u, 0u}, {0u, 32u, 0u}};
+        for (const auto& hdr : empties) {
+            std::stringstream s5(std::string(reinterpret_cast<const char*>(hdr), sizeof(hdr)));
+            db.assign(7, 1);
+            if (!ORB_SLAM2::ReadDescriptors(s5, db) || !db.empty()) return 7;
+        }
+    }
+    {
+        // the levels come to the host only when asked for: a call without fetchPyramid leaves mvImagePyramid as it
+        // was, ImagePyramid() fills it once
+        ORB_SLAM2::ORBextractorGpu lazy(500, 1.2f, 8, 20, 7, 0, W, H);
+        std::vector<orbx_keypoint> k3;
+        std::vector<uint8_t> d3;
+        lazy(img.data(), W, H, W, k3, d3);
+        if (lazy.mvImagePyramid[1].cols != 0) return 8;
+        const auto& pyr = lazy.ImagePyramid();
+        if (pyr[1].cols != ex.mvImagePyramid[1].cols || pyr[1].data != ex.mvImagePyramid[1].data) return 8;
+        lazy.SetFetchPyramid(true);
+        lazy(img.data(), W, H, W, k3, d3);
+        if (lazy.mvImagePyramid[2].data != ex.mvImagePyramid[2].data) return 8;
+    }
     // empty image: outputs untouched
     std::vector<orbx_keypoint> k2(3);
     std::vector<uint8_t> d2(5);

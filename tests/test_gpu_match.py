@@ -239,6 +239,54 @@ def test_stereo_then_extraction_on_another_stream():
     assert np.array_equal(ur0[0, :n0[0]], our) and np.array_equal(z0[0, :n0[0]], oz)
 
 
+def test_four_stereo_sets_in_flight():
+    """Four independent sets (two extractors and a matcher each: twelve streams over the four hardware queues a
+    process has) take turns for several rounds with no host synchronisation in between: extraction left, extraction
+    right and ComputeStereoMatches of a set are ordered by events only. Every set sees the same pairs, so every
+    set's result must equal the one a single set computes with a synchronisation after every call."""
+    import torch
+    npairs, nfeatures, nsets, rounds = 8, 1200, 4, 6
+    left = np.stack([m.synth_frame(500 + p) for p in range(npairs)])
+    right = np.stack([m.synth_frame(500 + p, right_view=True) for p in range(npairs)])
+    d_left, d_right = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    bf, b = 47.90639384423901, 47.90639384423901 / 435.2046959714599
+
+    def make_set():
+        exl = m.ORBextractor(nfeatures, 1.2, 8, 20, 7, max_batch=npairs)
+        exr = m.ORBextractor(nfeatures, 1.2, 8, 20, 7, max_batch=npairs)
+        cap = exl.capacity
+
+        def alloc():
+            return (torch.zeros((npairs, cap, 7), dtype=torch.float32, device="cuda"),
+                    torch.zeros((npairs, cap, 32), dtype=torch.uint8, device="cuda"),
+                    torch.zeros(npairs, dtype=torch.int32, device="cuda"))
+        return dict(exl=exl, exr=exr, L=alloc(), R=alloc(), hm=m.HammingMatcher(),
+                    ur=torch.full((npairs, cap), -7.0, dtype=torch.float32, device="cuda"),
+                    z=torch.full((npairs, cap), -7.0, dtype=torch.float32, device="cuda"))
+
+    def step(s):
+        s["exl"].extract_batch_device(d_left, *s["L"])
+        s["exr"].extract_batch_device(d_right, *s["R"])
+        s["hm"].compute_stereo_matches_device(s["exl"], s["exr"], *s["L"], *s["R"], bf, b, s["ur"], s["z"])
+
+    ref = make_set()
+    step(ref)
+    ref["hm"].synchronize()
+    torch.cuda.synchronize()
+    want_ur, want_z = ref["ur"].cpu().numpy(), ref["z"].cpu().numpy()
+    assert int((want_ur >= 0).sum()) > 50 * npairs
+    sets = [make_set() for _ in range(nsets)]
+    for r in range(rounds):
+        for s in sets:
+            step(s)
+    for s in sets:
+        s["hm"].synchronize()
+    torch.cuda.synchronize()
+    for k, s in enumerate(sets):
+        assert np.array_equal(s["ur"].cpu().numpy(), want_ur), "set %d" % k
+        assert np.array_equal(s["z"].cpu().numpy(), want_z), "set %d" % k
+
+
 @pytest.mark.parametrize("nshards", [1, 2, 3, 8])
 def test_packed_scan_and_merge_of_simulated_ranks(nshards):
     """The sharded-database path without a process group: every "rank" scans its contiguous shard into packed
