@@ -300,7 +300,7 @@ int orbx_search_for_initialization(orbx_matcher* m, const orbx_keypoint* keys1_u
  * the descriptor arrays orbx_extract_batch_device wrote for the two frames, d_keys2_un / d_cell_start2 /
  * d_cell_items2 frame 2's mvKeysUn and grid as orbx_undistort_assign_grid_device left them (device pointers, the
  * slices of one frame; descriptor arrays 16-byte aligned). Nothing is uploaded but one query per level-0 keypoint
- * of frame 1 (28 bytes each, read by the kernel from pinned host memory) and nothing comes back but, per query,
+ * of frame 1 (24 bytes each, read by the kernel from pinned host memory) and nothing comes back but, per query,
  * the number of its candidates and the eight closest of them in order, written into pinned host memory: one
  * launch and one wait. The candidate lists themselves stay in device memory; the host pass reads one back only
  * when those eight do not settle its query. keys1_un, keys2_un (host copies of mvKeysUn,

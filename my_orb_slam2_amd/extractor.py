@@ -136,6 +136,13 @@ class ORBextractor:
         b, h, w = d_images.shape
         if d_images.stride(2) != 1:
             raise ValueError("frames must have unit pixel stride")
+        # The kernels read level 0 in place with dword loads over whole padded rows: the last frame is read up to
+        # h * row_stride bytes, not just to its last pixel. A view whose storage ends earlier (a narrower window into
+        # a larger image that ends with the allocation) is copied to a dense tensor first.
+        need = (b - 1) * d_images.stride(0) + h * d_images.stride(1)
+        avail = d_images.untyped_storage().nbytes() - d_images.storage_offset() * d_images.element_size()
+        if avail < need:
+            d_images = d_images.contiguous()
         cap = d_descriptors.shape[1]
         assert d_keypoints.shape[0] == b and d_keypoints.shape[1] == cap and d_keypoints.element_size() * \
             d_keypoints.shape[2] == 28 and d_keypoints.is_contiguous() and d_descriptors.is_contiguous()

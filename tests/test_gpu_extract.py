@@ -314,6 +314,28 @@ def test_batch_with_padded_rows_and_gaps_between_frames():
         assert np.array_equal(d_desc[i, :cnt[i]].cpu().numpy(), want[i][1])
 
 
+def test_window_that_ends_with_its_allocation():
+    """An aligned window (row pitch and base multiples of 4) whose last padded row would run past the end of the
+    tensor's storage: the binding must not hand it to the in-place dword path as it is."""
+    import torch
+    B, W, H = 2, 752, 480
+    gpu, cpu = make(w=W, h=H, batch=B)
+    full = np.stack([m.synth_frame(70 + i, W, H) for i in range(B)])
+    d_full = torch.from_numpy(full).cuda()
+    d_view = d_full[:, :, 4:W]                         # 748 wide, pitch 752, starts 4 bytes into the storage
+    want = [cpu.extract(np.ascontiguousarray(full[i, :, 4:W])) for i in range(B)]
+    cap = gpu.capacity
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    gpu.extract_batch_device(d_view, d_kps, d_desc, d_cnt)
+    gpu.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    for i in range(B):
+        assert cnt[i] == len(want[i][0])
+        assert np.array_equal(d_desc[i, :cnt[i]].cpu().numpy(), want[i][1])
+
+
 def test_api_errors_and_empty_image():
     gpu, _ = make()
     k, d = gpu(np.empty((0, 0), np.uint8))

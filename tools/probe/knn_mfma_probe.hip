@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void knn2_mfma_kernel(const uint32_t* __res
 // FP4 only; a lane reads 16 contiguous bytes of its row (half h of the row: dwords 4h .. 4h+3; matrix instruction m
 // takes dword 4h + m from both operands), tiles go in pairs on two accumulator sets when PAIR is set, and the update path is
 // branch-free when many lanes have a row to take and filtered register by register otherwise.
-template <int NQB, bool PAIR, int WPS, bool UNSCALED = false>
+template <int NQB, bool PAIR, int WPS, bool UNSCALED = false, int DIAG = 0>
 __global__ __launch_bounds__(256, WPS) void knn2_fp4_kernel(const uint32_t* __restrict__ query, int64_t nq,
                                                             const uint32_t* __restrict__ db, int64_t ndb,
                                                             int64_t chunkRows, int64_t indexBase,
@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256, WPS) void knn2_fp4_kernel(const uint32_t* __re
         const float mn = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), acc[15]));
         const unsigned long long hit = __builtin_amdgcn_ballot_w64(mn < thr[b]);
         if (hit == 0) return;
+        if (DIAG == 1) { k1[b] = min(k1[b], (unsigned)hit); return; }     // ceiling probe: no update path (wrong results)
         // key = (acc + |q|) << 23 | row; rows past the chunk's end (last step only) never enter
         const unsigned base = ((unsigned)pq[b] << 23) + (unsigned)rowBase;
         if (__popcll(hit) > 6) {
@@ -339,7 +340,25 @@ __global__ __launch_bounds__(256, WPS) void knn2_fp4_kernel(const uint32_t* __re
             for (int k = 0; k < 4; k++) A[m][k] = lut[(raw[m] >> (8 * k)) & 255u];
         if (rb + 1 < nrb) raw = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff, (rb + 1) * 1024, 0));
         const int rowBase = rb * 32 + 4 * h;
-        if (PAIR) {
+        if (PAIR && DIAG == 2) {
+            // both tiles' matrix instructions, both min trees, ONE branch for the pair
+#pragma unroll
+            for (int b = 0; b < NQB; b += 2) {
+                const v16f x = tile(A, b);
+                const v16f y = tile(A, b + 1);
+                auto tmin = [&](const v16f& acc) {
+                    const float m0 = fminf(fminf(acc[0], acc[1]), acc[2]), m1 = fminf(fminf(acc[3], acc[4]), acc[5]);
+                    const float m2 = fminf(fminf(acc[6], acc[7]), acc[8]), m3 = fminf(fminf(acc[9], acc[10]), acc[11]);
+                    const float m4 = fminf(fminf(acc[12], acc[13]), acc[14]);
+                    return fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), acc[15]));
+                };
+                const float mx = tmin(x) - thr[b], my = tmin(y) - thr[b + 1];
+                if (__builtin_amdgcn_ballot_w64(fminf(mx, my) < 0.0f) != 0) {
+                    epilogue(x, b, rowBase);
+                    epilogue(y, b + 1, rowBase);
+                }
+            }
+        } else if (PAIR) {
 #pragma unroll
             for (int b = 0; b < NQB; b += 2) {
                 const v16f x = tile(A, b);
@@ -582,6 +601,9 @@ int main(int argc, char** argv) {
         else if (mode == 8) go(knn2_fp4_kernel<8, true, 2>, 8);
         else if (mode == 9) go(knn2_fp4s_kernel<8, 2>, 8);
         else if (mode == 12) go(knn2_fp4_kernel<8, false, 2, true>, 8);
+        else if (mode == 14) go(knn2_fp4_kernel<8, false, 2, true, 1>, 8);
+        else if (mode == 15) go(knn2_fp4_kernel<6, true, 2, true, 2>, 6);
+        else if (mode == 16) go(knn2_fp4_kernel<4, true, 2, true, 2>, 4);
         else if (mode == 13) go(knn2_fp4_kernel<2, false, 2, true>, 2);
         else if (mode == 10) go(knn2_fp4s_kernel<2, 2>, 2);
         else if (mode == 11) go(knn2_fp4s_kernel<4, 2>, 4);
@@ -631,7 +653,7 @@ int main(int argc, char** argv) {
         }
     }
     printf("{\"mode\": \"%s\", \"expand\": %d, \"nq\": %lld, \"ndb\": %lld, \"chunk_rows\": %lld, \"ms\": %.3f, \"pairs_per_s\": %.4g, \"checked\": %s, \"wrong\": %lld}\n",
-           mode == 0 ? "i8" : mode == 1 ? "fp4" : mode == 2 ? "fp4_v2_8" : mode == 3 ? "fp4_v2_6pair" : mode == 4 ? "fp4_v2_2pair" : mode == 5 ? "fp4_v2_1" : mode == 6 ? "fp4_v2_16pair_1wave" : mode == 7 ? "fp4_v2_4pair" : mode == 8 ? "fp4_v2_8pair" : mode == 9 ? "fp4_v3_8" : mode == 10 ? "fp4_v3_2" : mode == 11 ? "fp4_v3_4" : mode == 12 ? "fp4_v2_8_unscaled" : "fp4_v2_2_unscaled", expand, (long long)nq, (long long)ndb, (long long)chunkRows, ms, (double)nq * ndb / (ms * 1e-3),
+           mode == 0 ? "i8" : mode == 1 ? "fp4" : mode == 2 ? "fp4_v2_8" : mode == 3 ? "fp4_v2_6pair" : mode == 4 ? "fp4_v2_2pair" : mode == 5 ? "fp4_v2_1" : mode == 6 ? "fp4_v2_16pair_1wave" : mode == 7 ? "fp4_v2_4pair" : mode == 8 ? "fp4_v2_8pair" : mode == 9 ? "fp4_v3_8" : mode == 10 ? "fp4_v3_2" : mode == 11 ? "fp4_v3_4" : mode == 12 ? "fp4_v2_8_unscaled" : mode == 13 ? "fp4_v2_2_unscaled" : mode == 14 ? "fp4_v2_8_no_update_path" : mode == 15 ? "fp4_v2_6_joint_pair" : "fp4_v2_4_joint_pair", expand, (long long)nq, (long long)ndb, (long long)chunkRows, ms, (double)nq * ndb / (ms * 1e-3),
            check ? "true" : "false", bad);
     return bad ? 3 : 0;
 }
