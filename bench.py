@@ -231,14 +231,14 @@ class Rank:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(self, fn, steps, warmup, min_seconds=0.0):
+    def timed(self, fn, steps, warmup, min_seconds=None):
         """warmup untimed steps, then exactly `steps` steps between two fences; maximum over ranks, in seconds.
         With min_seconds the `steps` steps are repeated in whole rounds (every rank the same number, taken from
         the slowest rank's first round) until the timed region is that long; returns (seconds, rounds)."""
         for i in range(warmup):
             fn(i)
         rounds = 1
-        if min_seconds > 0:
+        if min_seconds is not None and min_seconds > 0:
             self.fence()
             t0 = time.perf_counter()
             for i in range(steps):
@@ -253,7 +253,7 @@ class Rank:
         self.fence()
         self.last_own_seconds = time.perf_counter() - t0
         dt = self.max_over_ranks(self.last_own_seconds)
-        return (dt, rounds) if min_seconds > 0 else dt
+        return (dt, rounds) if min_seconds is not None else dt
 
     def gather_own_seconds(self):
         """Every rank's own time for the last timed region (rank order), for the per-rank figures."""

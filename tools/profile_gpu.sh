@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --steps 10 --warmup 1 --launches 1 --unique 256 --contexts 1 --no-cpu-baseline --min-seconds 0 --legs="
+ARGS="$ROOT/bench.py --steps 200 --warmup 20 --launches 1 --unique 256 --contexts 1 --no-cpu-baseline --min-seconds 0 --legs="
 cd /tmp
 timeout -k 10 170 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 $ARGS > "$OUT/stats_bench.json"
 pmc() {
