@@ -32,6 +32,31 @@ def test_knn2_matches_oracle(nq, ndb):
         assert np.array_equal(idx, oi) and np.array_equal(d1, o1) and np.array_equal(d2, o2)
 
 
+@pytest.mark.parametrize("nq,ndb,blocks", [(4000, 600000, 2), (33000, 600000, 8)])
+def test_knn2_scan_plans_with_more_queries_per_wave(nq, ndb, blocks):
+    """Sizes at which the scan keeps two and eight blocks of 32 queries per wave (the small cases above all run with
+    one): a wave's operand registers, the merge of a query's two half-lanes and the chunk fold are the same code,
+    but unrolled differently. A sample of the queries is checked against the oracle, all of them for consistency."""
+    rng = np.random.default_rng(nq + blocks)
+    q, db = planted(rng, 512, ndb)
+    q = np.concatenate([q, rng.integers(0, 256, (nq - 512, 32), dtype=np.uint8)])
+    db[ndb // 3] = db[ndb // 7]                            # an exact duplicate: lowest row must win
+    q[5] = db[ndb // 3]
+    q[nq - 1] = db[ndb - 1]                                # last row of the last chunk, last query of the last wave
+    hm = m.HammingMatcher()
+    idx, d1, d2 = hm.knn2(q, db)
+    pick = np.concatenate([np.arange(0, 96), np.arange(nq - 32, nq)])
+    oi, o1, o2 = orc.knn2(q[pick], db)
+    assert np.array_equal(idx[pick], oi) and np.array_equal(d1[pick], o1) and np.array_equal(d2[pick], o2)
+    assert idx[5] == ndb // 7 and d1[5] == 0 and d2[5] == 0
+    assert idx[nq - 1] == ndb - 1 and d1[nq - 1] == 0
+    assert np.all(d1 <= d2) and np.all(idx >= 0) and np.all(idx < ndb)
+    # the database rows really are what came back
+    rows = db[idx[:2000]]
+    dist = np.unpackbits(rows ^ q[:2000], axis=1).sum(axis=1)
+    assert np.array_equal(dist, d1[:2000])
+
+
 def test_knn2_ties_and_duplicates():
     rng = np.random.default_rng(9)
     base = rng.integers(0, 256, (50, 32), dtype=np.uint8)
