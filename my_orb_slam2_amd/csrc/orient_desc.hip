@@ -62,16 +62,22 @@ constexpr int kHIters = 3, kVIters = 3; // 64-item rounds of the row pass and of
 static_assert(kBlRows == kBlurPatchRows && kTPitch == kBlurPatchPitch && kPR - 3 == kBlurPatchCy && kCx == kBlurPatchCx,
               "the probe's patch shape is the kernel's");
 
-// Byte weights for the intensity-centroid sums, four columns per dword: patch row v + 15 (32, the last
-// one all zero) x dword q (8), column u = 4q - 15 + byte. .x: 1 inside the disc (plain row sum);
-// .y: u + 15 inside the disc.
+// Byte weights for the intensity-centroid sums, four columns per dword, in the order the lanes fetch them: round q
+// (4) x lane (64) -> patch row v + 15 = 8q + moment_row(lane) (32 rows, the last one all zero), dword lane & 7,
+// column u = 4 (lane & 7) - 15 + byte. .x: 1 inside the disc (plain row sum); .y: u + 15 inside the disc.
+// moment_row puts the even rows of a block of eight on the lower half-wave and the odd rows on the upper one: with
+// 12 dwords per raw row, four rows two apart start 8 banks apart, so the 32 dwords a half-wave reads cover each
+// bank once (rows 0..3 together would put rows 0 and 3 on the same four banks).
+__host__ __device__ constexpr int moment_row(int lane) { return 2 * ((lane >> 3) & 3) + (lane >> 5); }
 struct MomentWeights {
-    uint32_t w[32][8][2];
+    uint32_t w[4][64][2];
 };
 constexpr MomentWeights make_moment_weights() {
     MomentWeights m{};
-    for (int row = 0; row < 31; row++)
-        for (int q = 0; q < 8; q++) {
+    for (int qq = 0; qq < 4; qq++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int row = 8 * qq + moment_row(lane), q = lane & 7;
+            if (row >= 31) continue;
             const int av = row < 15 ? 15 - row : row - 15;
             uint32_t w0 = 0, w1 = 0;
             for (int b = 0; b < 4; b++) {
@@ -82,8 +88,8 @@ constexpr MomentWeights make_moment_weights() {
                     w1 |= (uint32_t)(u + 15) << (8 * b);
                 }
             }
-            m.w[row][q][0] = w0;
-            m.w[row][q][1] = w1;
+            m.w[qq][lane][0] = w0;
+            m.w[qq][lane][1] = w1;
         }
     return m;
 }
@@ -111,10 +117,14 @@ constexpr bool rowsum_group_needed(int r, int gg) {
 }
 // T holds, for every needed (row pair j, column group gg), one 16-byte cell: the packed sums of rows 2j, 2j+1 in
 // the group's four columns. Cells of one group are consecutive in j (the pairs a group needs are a contiguous run,
-// the disc being convex), so the four pairs a column-pass item reads are 16 bytes apart; the groups are stored in
-// the order kTGroupOrder, found by search: with it the cells that neighbouring lanes (neighbouring groups of one
-// pair) touch fall into different 16-byte bank groups, so the 16-byte LDS accesses do not collide.
-constexpr int kTGroupOrder[10] = {2, 4, 3, 5, 10, 1, 8, 6, 7, 9};
+// the disc being convex), so the four pairs a column-pass item reads are 16 bytes apart. The order of the groups
+// (kTGroupOrder) and the lane each work item runs on (kRowItemSlot, kColItemSlot below) are free choices: the
+// items of a pass are independent. tools/lds/orient_desc_lds_search.py picks them so that the lanes an LDS
+// instruction serves together (half-waves for dword accesses, groups of 8 for 16-byte stores, four interleaved
+// groups of 16 for 16-byte loads) fall on different banks: 20 extra LDS cycles per keypoint in both passes,
+// where the plain order (items ascending by row pair, then group) takes 136. 18 of the 20 are a floor: the raw
+// rows' 48-byte pitch puts up to nine items on one bank residue and a pass has six half-waves.
+constexpr int kTGroupOrder[10] = {3, 1, 7, 9, 10, 6, 2, 4, 5, 8};
 struct TLayout {
     int lo[11], hi[11], start[11];      // per group: first and last needed pair, first cell
     int cells;
@@ -146,7 +156,25 @@ constexpr int t_cell_offset(int j, int gg) { return 16 * (kTLayout.start[gg] + j
 // Work items. Row pass: patch row pair j, group gg -> (byte offset in R of the dword left of the group in
 // row 2j) | (byte offset in T of the cell) << 16. Column pass: blurred row pair p, group gg ->
 // (byte offset in T of pair p's cell; pairs p+1 .. p+3 follow it) | (byte offset in Bl of row 2p's dword) << 16.
-// Spare slots repeat item 0 (same inputs, same stores).
+// Slot s (round s / 64, lane s % 64) runs the item whose number, counting the needed (pair, group) combinations by
+// pair and then by group, is kRowItemSlot[s] / kColItemSlot[s]. Spare slots repeat an item of their own lane
+// group (same addresses as a neighbouring lane, same stores).
+constexpr unsigned char kRowItemSlot[kHIters * 64] = {
+     83, 113,  62, 124,   8, 126,  94, 103, 122, 170,  47,   1,  35, 140,   7, 177,  99, 125,  38, 151,  36,  31, 164,  29,  39, 137,  20, 105,  51, 117, 112,  64,
+     90, 157,  88,  19,  45,  89,  84, 134, 155, 188,  54, 143, 154,   9, 147,  79, 178,   2, 127, 181,  33, 114,  26, 161,  71, 171,  30, 180,  52,  11,  22,  61,
+     40, 118, 132,  98, 121, 133,  48,  46, 108, 167, 184,  70, 190, 156,  14, 141,  10,  56, 173, 165, 119, 142,  69,  91,  67,  21,  77, 185,  63, 186,  27, 176,
+    189,  34,  76,  43,  72,  37,  87, 158,  75, 169, 104, 174, 106,  28,   6,  96, 168,  42, 179, 175,  60,  32, 128, 110, 102, 182,  13,  16, 101, 160,  68,  17,
+     57, 129, 135,  81, 163,  74, 183, 116,  55,  80,  92,   5,  58, 115, 111, 159, 139, 145,  44, 172,  86, 153,  53, 149, 152,  82,  12, 146,  85, 131, 130,   0,
+    123, 100,  78,   4,  93, 120, 150,  97,   3, 136,  15,  23, 109, 144,  65,  41,  95,  66,  24,  73,  50, 187,  25, 138, 148, 148,  49, 107, 166,  59,  18, 162,
+};
+constexpr unsigned char kColItemSlot[kVIters * 64] = {
+    101, 101,  56,   0, 146,  43, 115, 146,  36, 158,   9,  65, 101,  76,  70,  44, 146,   8, 157,  78,  90, 101, 151,  10, 123, 160,  80,  89,  17,  75,  83, 135,
+     18,  18,  14, 122, 105,   7,  81, 106, 120, 159,  60, 138, 113,  61,  71,  16, 105, 136,  22,  86,  18,  47,  73, 125,  51,  26, 143,  93,  62,  69, 130, 103,
+      4, 108, 107,  29,  98, 129,  59,  98, 145, 102, 114,  98,  31, 142,  92,   4,  91,  98,  98,  49,   4,  95, 137,  35,   4,  94,  99,  85, 133,  33,   6,  15,
+    112,  27,  40,  64,  55, 152,  55, 140,  30,  55,  72,  55,  20, 112, 141, 112,  55,  19,  77,  79,  50, 117, 119, 104,  97, 110,  37,  58,  55,  87, 147,  48,
+     41, 153,  52,  41,  23,  54, 156,  74, 148,  53, 131,  39,  84,  68,  63,  11,  23,  66,  24,  42, 128, 155,  41,   1,  41,  45,  88,   2,  13,  57,  23,   3,
+    139, 139,  32, 144,  25,  82, 127, 126, 109,  25, 134,  25,  21, 121,  34,  96, 150, 100, 149, 124,  46, 139,  28,  38, 154, 118, 111,   5,  12, 116, 132,  67,
+};
 struct ItemTables {
     uint32_t h[kHIters * 64];
     uint32_t v[kVIters * 64];
@@ -155,6 +183,7 @@ struct ItemTables {
 };
 constexpr ItemTables make_item_tables() {
     ItemTables t{};
+    uint32_t hn[kHIters * 64] = {}, vn[kVIters * 64] = {};
     int nh = 0, nv = 0;
     bool ok = true;
     for (int j = 0; j < kTPairs; j++)
@@ -162,7 +191,7 @@ constexpr ItemTables make_item_tables() {
             if (rowsum_group_needed(2 * j, gg) || rowsum_group_needed(2 * j + 1, gg)) {
                 ok = ok && j >= kTLayout.lo[gg] && j <= kTLayout.hi[gg];
                 if (nh < kHIters * 64)
-                    t.h[nh] = (uint32_t)(2 * j * kRPitch + (gg - 1) * 4) | (uint32_t)t_cell_offset(j, gg) << 16;
+                    hn[nh] = (uint32_t)(2 * j * kRPitch + (gg - 1) * 4) | (uint32_t)t_cell_offset(j, gg) << 16;
                 nh++;
             }
     for (int p = 0; 2 * p < kBlRows; p++)
@@ -170,19 +199,31 @@ constexpr ItemTables make_item_tables() {
             if (blur_group_needed(2 * p, gg) || blur_group_needed(2 * p + 1, gg)) {
                 ok = ok && p >= kTLayout.lo[gg] && p + 3 <= kTLayout.hi[gg];      // all four pairs are stored
                 if (nv < kVIters * 64)
-                    t.v[nv] = (uint32_t)t_cell_offset(p, gg) | (uint32_t)(2 * p * kTPitch + 4 * gg) << 16;
+                    vn[nv] = (uint32_t)t_cell_offset(p, gg) | (uint32_t)(2 * p * kTPitch + 4 * gg) << 16;
                 nv++;
             }
     t.nh = nh;
     t.nv = nv;
+    // every item sits on at least one slot, and no slot names an item that does not exist
+    bool hSeen[kHIters * 64] = {}, vSeen[kVIters * 64] = {};
+    for (int s = 0; s < kHIters * 64; s++) {
+        ok = ok && kRowItemSlot[s] < nh;
+        t.h[s] = hn[kRowItemSlot[s]];
+        hSeen[kRowItemSlot[s]] = true;
+    }
+    for (int s = 0; s < kVIters * 64; s++) {
+        ok = ok && kColItemSlot[s] < nv;
+        t.v[s] = vn[kColItemSlot[s]];
+        vSeen[kColItemSlot[s]] = true;
+    }
+    for (int i = 0; i < nh && i < kHIters * 64; i++) ok = ok && hSeen[i];
+    for (int i = 0; i < nv && i < kVIters * 64; i++) ok = ok && vSeen[i];
     t.ok = ok;
-    for (int i = nh; i < kHIters * 64; i++) t.h[i] = t.h[0];
-    for (int i = nv; i < kVIters * 64; i++) t.v[i] = t.v[0];
     return t;
 }
 constexpr ItemTables kItems = make_item_tables();
 static_assert(kItems.nh <= kHIters * 64 && kItems.nv <= kVIters * 64, "work item tables overflow");
-static_assert(kItems.nh == kTItems && kItems.ok, "a work item points outside the stored part of T");
+static_assert(kItems.nh == kTItems && kItems.ok, "a work item points outside the stored part of T, or the slot tables miss an item");
 __device__ const ItemTables c_items = make_item_tables();
 
 
@@ -440,14 +481,15 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
     // window (columns 8..39 of R): row sums with 0/1 byte weights, sum (u+15)*I with byte weights
     int s0 = 0, s1 = 0, m01 = 0;
     {
-        const uint32_t* Rw = R32 + (kPR - kHalfPatch) * 12 + (kCx - kHalfPatch) / 4 + (lane >> 3) * 12 + (lane & 7);
+        const int mrow = moment_row(lane);
+        const uint32_t* Rw = R32 + (kPR - kHalfPatch) * 12 + (kCx - kHalfPatch) / 4 + mrow * 12 + (lane & 7);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t D = Rw[q * 8 * 12];
             const uint2 w = momw[q];
             const uint32_t rs = __builtin_amdgcn_udot4(D, w.x, 0u, false);
             s0 += (int)rs;
-            m01 += __mul24((lane >> 3) + 8 * q - kHalfPatch, (int)rs);
+            m01 += __mul24(mrow + 8 * q - kHalfPatch, (int)rs);
             s1 = (int)__builtin_amdgcn_udot4(D, w.y, (uint32_t)s1, false);
         }
     }
