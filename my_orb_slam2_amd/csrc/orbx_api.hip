@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -116,8 +117,15 @@ int dev_alloc(T** p, size_t count) {
     return ORBX_OK;
 }
 
+// Set-up steps that allocate, free or copy synchronously (table uploads, staging buffers) and the recording of a launch
+// chain into a HIP graph exclude each other across the host threads of the process: a device-wide synchronisation
+// issued by one thread while another thread's stream is recording invalidates that recording. Both are rare (once per
+// context and geometry) and short.
+std::mutex g_setupMutex;
+
 int ensure_geometry(orbx_ctx* c, int w, int h) {
     if (c->haveGeom && c->geom.width == w && c->geom.height == h) return ORBX_OK;
+    std::lock_guard<std::mutex> setup(g_setupMutex);
     std::string err;
     PyramidGeom g;
     if (!build_geometry(w, h, c->tab, g, err)) {
@@ -451,6 +459,7 @@ int ensure_staging(orbx_ctx* c, int cap) {
     int rc = ensure_stage_img(c);
     if (rc) return rc;
     if (cap > c->stageCap) {
+        std::lock_guard<std::mutex> setup(g_setupMutex);
         HIP_TRY(hipStreamSynchronize(c->stream));
         drop_replays(c);
         if (c->stageOut) HIP_TRY(hipFree(c->stageOut));
@@ -516,44 +525,58 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, const uint8_t* images, int nframe
             for (auto& r : c->replays)
                 if (r.w == width && r.h == height && r.n == nframes && r.cap == cap) exec = r.exec;
             if (!exec) {
+                // Recorded once per (geometry, frames, capacity). A recording that does not come out whole (another
+                // part of the process may have synchronised the device meanwhile) is dropped and this context goes
+                // on without replays: the plain path below issues the same launches.
+                std::lock_guard<std::mutex> setup(g_setupMutex);
                 hipGraph_t graph = nullptr;
-                HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-                c->capturing = true;
-                hipError_t e1 = hipMemcpyAsync(c->stageImg, c->pinIn, fstride * (size_t)nframes, hipMemcpyHostToDevice, c->stream);
-                int r1 = orbx_extract_batch_device(c, c->stageImg, nframes, width, height, pitch, fstride,
+                hipError_t e0 = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
+                int r1 = ORBX_OK;
+                hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess, e4 = hipSuccess;
+                if (e0 == hipSuccess) {
+                    c->capturing = true;
+                    e1 = hipMemcpyAsync(c->stageImg, c->pinIn, fstride * (size_t)nframes, hipMemcpyHostToDevice, c->stream);
+                    r1 = orbx_extract_batch_device(c, c->stageImg, nframes, width, height, pitch, fstride,
                                                    reinterpret_cast<orbx_keypoint*>(c->stageOut + lay.kps),
                                                    c->stageOut + lay.desc, cap, reinterpret_cast<int32_t*>(c->stageOut),
                                                    c->stream);
-                hipError_t e2 = hipMemcpyAsync(c->pinOut, c->stageOut, lay.total, hipMemcpyDeviceToHost, c->stream);
-                c->capturing = false;
-                hipError_t e3 = hipStreamEndCapture(c->stream, &graph);
-                if (r1) { if (graph) (void)hipGraphDestroy(graph); return r1; }
-                HIP_TRY(e1);
-                HIP_TRY(e2);
-                HIP_TRY(e3);
-                hipError_t e4 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);
-                HIP_TRY(e4);
-                if (c->replays.size() >= 4) {
-                    (void)hipGraphExecDestroy(c->replays.front().exec);
-                    c->replays.erase(c->replays.begin());
+                    e2 = hipMemcpyAsync(c->pinOut, c->stageOut, lay.total, hipMemcpyDeviceToHost, c->stream);
+                    c->capturing = false;
+                    e3 = hipStreamEndCapture(c->stream, &graph);
                 }
-                c->replays.push_back(orbx_ctx::Replay{width, height, nframes, cap, exec});
+                if (e0 == hipSuccess && r1 == ORBX_OK && e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && graph)
+                    e4 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                else
+                    e4 = hipErrorUnknown;
+                if (graph) (void)hipGraphDestroy(graph);
+                if (e4 != hipSuccess || !exec) {
+                    (void)hipGetLastError();
+                    exec = nullptr;
+                    c->useGraph = false;
+                } else {
+                    if (c->replays.size() >= 4) {
+                        (void)hipGraphExecDestroy(c->replays.front().exec);
+                        c->replays.erase(c->replays.begin());
+                    }
+                    c->replays.push_back(orbx_ctx::Replay{width, height, nframes, cap, exec});
+                }
             }
-            HIP_TRY(hipGraphLaunch(exec, c->stream));
-            c->lastStream = c->stream;
-            HIP_TRY(record_event(c->evDone, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            const int32_t* hc = reinterpret_cast<const int32_t*>(c->pinOut);
-            for (int f = 0; f < nframes; f++) {
-                counts[f] = hc[f];
-                const size_t n = (size_t)std::min(std::max(hc[f], 0), cap);
-                std::memcpy(kps + (size_t)f * cap, c->pinOut + lay.kps + (size_t)f * cap * sizeof(orbx_keypoint),
-                            n * sizeof(orbx_keypoint));
-                std::memcpy(desc + (size_t)f * cap * ORBX_DESC_BYTES, c->pinOut + lay.desc + (size_t)f * cap * ORBX_DESC_BYTES,
-                            n * ORBX_DESC_BYTES);
+            if (exec) {
+                HIP_TRY(hipGraphLaunch(exec, c->stream));
+                c->lastStream = c->stream;
+                HIP_TRY(record_event(c->evDone, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                const int32_t* hc = reinterpret_cast<const int32_t*>(c->pinOut);
+                for (int f = 0; f < nframes; f++) {
+                    counts[f] = hc[f];
+                    const size_t n = (size_t)std::min(std::max(hc[f], 0), cap);
+                    std::memcpy(kps + (size_t)f * cap, c->pinOut + lay.kps + (size_t)f * cap * sizeof(orbx_keypoint),
+                                n * sizeof(orbx_keypoint));
+                    std::memcpy(desc + (size_t)f * cap * ORBX_DESC_BYTES, c->pinOut + lay.desc + (size_t)f * cap * ORBX_DESC_BYTES,
+                                n * ORBX_DESC_BYTES);
+                }
+                return ORBX_OK;
             }
-            return ORBX_OK;
         }
         HIP_TRY(hipMemcpyAsync(c->stageImg, c->pinIn, fstride * (size_t)nframes, hipMemcpyHostToDevice, c->stream));
     } else if (row_stride == pitch && frame_stride == fstride) {
