@@ -147,35 +147,31 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     const int f = blockIdx.x;                         // frame-fastest grid: one frame per XCD
     const int cell = blockIdx.y * kCellsPerBlock + wv;
     if (cell >= g.totalCells) return;
-    int l = 0;
-    while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellBase) l++;
-    const LevelGeom& L = g.lv[l];
-    const int c = cell - L.cellBase;
-    // c / nCols without a division (the multiplier of a one-column grid would not fit 32 bits)
-    const int ci = L.nCols == 1 ? c : (int)__umulhi((uint32_t)c, L.colsMagic), cj = c - ci * L.nCols;
-
+    // the cell's record: rectangle in level coordinates (:783-798), its level's place in the pyramid, its slots
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    const u32x8 rec = *reinterpret_cast<const u32x8 __attribute__((address_space(4)))*>(
+        reinterpret_cast<uintptr_t>(fs.cells + cell));
     int32_t* countOut = fs.cellCount + (long long)f * g.totalCells + cell;
-    uint32_t* slotOut = fs.slots + (long long)f * g.totalSlots + L.slotBase + (long long)c * L.slotCap;
-
-    // cell rectangle in level coordinates (:783-798)
-    const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
-    const int iniX = kBorder + cj * L.wCell, iniY = kBorder + ci * L.hCell;
-    const int maxX = min(iniX + L.wCell + 6, maxBX), maxY = min(iniY + L.hCell + 6, maxBY);
-    const int sw = maxX - iniX - 6, sh = maxY - iniY - 6;  // scanned rectangle (3-px FAST margin)
-    if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || sw <= 0 || sh <= 0) {
+    if (rec[6] >> 31) {                                // the reference skips this cell
         if (lane == 0) *countOut = 0;
         return;
     }
+    const int iniX = (int)(rec[0] & 0xFFFFu), iniY = (int)(rec[0] >> 16);
+    const int maxX = (int)(rec[1] & 0xFFFFu), maxY = (int)(rec[1] >> 16);
+    const int sw = maxX - iniX - 6, sh = maxY - iniY - 6;  // scanned rectangle (3-px FAST margin)
     const int th = maxY - iniY;
+    const int slotCap = (int)(rec[6] & 0xFFFFu);
+    const int levelH = (int)(rec[5] >> 8);
+    uint32_t* slotOut = fs.slots + (long long)f * g.totalSlots + rec[2];
 
     const uint8_t* img;
     long long rowStride;
-    if (l == 0) {
+    if ((rec[5] & 0xFFu) == 0) {
         img = fs.img + (long long)f * fs.imgFrameStride;
         rowStride = fs.imgRowStride;
     } else {
-        img = fs.pyr + (long long)f * g.pyrBytes + L.offset;
-        rowStride = L.stride;
+        img = fs.pyr + (long long)f * g.pyrBytes + rec[3];
+        rowStride = rec[4];
     }
 
     // ---- 1. stage the cell in LDS ----
@@ -203,16 +199,18 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         const int stride32 = (int)rowStride;                                  // a level is < 2^31 bytes
         const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, L.h * stride32, 0x00027000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, levelH * stride32, 0x00027000);
         const int laneOff = (int)__umul24((uint32_t)tr, (uint32_t)stride32) + xa + td * 4;
         const int lastGroup = ((th - 1) / kRowsPerStep) * kRowsPerStep;
+        const int lastOff = (iniY + lastGroup) * stride32, stepOff = kRowsPerStep * stride32;
         if (td < ndw) {
             for (int r0 = 0; r0 < th; r0 += kTileRowBatch) {
                 u32x2 v[kBatch];
+                int rowOff = (iniY + r0) * stride32;                                           // wave-uniform
 #pragma unroll
                 for (int q = 0; q < kBatch; q++) {
-                    const int row = iniY + min(r0 + kRowsPerStep * q, lastGroup);               // wave-uniform
-                    v[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, laneOff, row * stride32, 0);
+                    v[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, laneOff, min(rowOff, lastOff), 0);
+                    rowOff += stepOff;
                 }
 #pragma unroll
                 for (int q = 0; q < kBatch; q++)
@@ -358,14 +356,14 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
             constexpr int kRecip = ((1 << 20) + PITCH - 1) / PITCH;
             const int y = (int)(__umul24((uint32_t)e, (uint32_t)kRecip) >> 20), x = e - y * PITCH;
             // FAST reports sub-image coordinates (x+3, y+3); the caller adds j*wCell, i*hCell (:814-815)
-            if (pos < L.slotCap) slotOut[pos] = pack_cand(cj * L.wCell + x + 3, ci * L.hCell + y + 3, sc);
+            if (pos < slotCap) slotOut[pos] = pack_cand(iniX - kBorder + x + 3, iniY - kBorder + y + 3, sc);
         }
         nout += __popcll(m);
     }
     if (nout > 0 || iniTh == minTh) break;
     wave_sync();
     }
-    if (lane == 0) *countOut = min(nout, L.slotCap);
+    if (lane == 0) *countOut = min(nout, slotCap);
 }
 
 hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nframes, int iniTh, int minTh,

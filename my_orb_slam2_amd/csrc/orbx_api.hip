@@ -64,6 +64,7 @@ struct orbx_ctx {
     bool haveGeom = false;
     ResizeTab resize[ORBX_MAX_LEVELS];
     void* resizeBlob = nullptr;
+    void* cellBlob = nullptr;     // CellRecord[totalCells] of the current geometry
     FusedPlan fused;              // grouped pyramid launches for this geometry (empty: one launch per level)
     void* fusedBlob = nullptr;
     // device buffers sized for max_width x max_height x max_batch
@@ -152,6 +153,7 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
     HIP_TRY(hipStreamSynchronize(c->stream));   // the old tables may still be in use
     if (c->lastStream && c->lastStream != c->stream) HIP_TRY(hipStreamSynchronize(c->lastStream));
     drop_replays(c);                            // recorded launches carry the old tables' addresses
+    c->haveGeom = false;                        // until the new tables are all in place
     if (c->resizeBlob) HIP_TRY(hipFree(c->resizeBlob));
     c->resizeBlob = nullptr;
     HIP_TRY(hipMalloc(&c->resizeBlob, blob.size()));
@@ -189,6 +191,19 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
         c->resize[l].xentry = reinterpret_cast<const int32_t*>(put(xe.data(), xe.size() * 4));
     }
     HIP_TRY(hipMemcpy(c->resizeBlob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    {
+        std::vector<CellRecord> cells;
+        if (!build_cell_table(g, cells)) {
+            set_error("image %dx%d: a FAST cell does not fit its table record", w, h);
+            return ORBX_ERR_INVALID;
+        }
+        if (c->cellBlob) HIP_TRY(hipFree(c->cellBlob));
+        c->cellBlob = nullptr;
+        c->fs.cells = nullptr;
+        HIP_TRY(hipMalloc(&c->cellBlob, std::max<size_t>(cells.size(), 1) * sizeof(CellRecord)));
+        if (!cells.empty()) HIP_TRY(hipMemcpy(c->cellBlob, cells.data(), cells.size() * sizeof(CellRecord), hipMemcpyHostToDevice));
+        c->fs.cells = static_cast<const CellRecord*>(c->cellBlob);
+    }
     // grouped pyramid launches: range tables next to the resize tables
     if (c->fusedBlob) HIP_TRY(hipFree(c->fusedBlob));
     c->fusedBlob = nullptr;
@@ -305,7 +320,7 @@ extern "C" void orbx_destroy(orbx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_replays(c);
     void* bufs[] = {c->fs.pyr, c->fs.cellCount, c->fs.slots, c->fs.cand, c->fs.nid, c->fs.sel,
-                    c->fs.selCount, c->resizeBlob, c->fusedBlob, c->stageImg, c->stageOut};
+                    c->fs.selCount, c->resizeBlob, c->cellBlob, c->fusedBlob, c->stageImg, c->stageOut};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (c->pinOut) (void)hipHostFree(c->pinOut);

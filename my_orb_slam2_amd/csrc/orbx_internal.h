@@ -56,12 +56,28 @@ struct PyramidGeom {
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
 
+// One FAST cell of a frame as the kernel needs it, made on the host once per image size: a wave fetches its cell's
+// record with one scalar 32-byte load instead of walking the level table and redoing the rectangle arithmetic
+// (src/ORBextractor.cc:783-798) with scalar instructions.
+struct CellRecord {
+    uint32_t ini;           // iniX | iniY << 16 (level coordinates of the cell's first column and row)
+    uint32_t max;           // maxX | maxY << 16 (one past its last column and row, FAST margins included)
+    uint32_t slotOff;       // first entry of the cell inside a frame's slot array
+    uint32_t levelOff;      // byte offset of the cell's level inside a frame's pyramid buffer (levels >= 1)
+    uint32_t stride;        // row pitch of that level in bytes (levels >= 1; level 0 has the caller's pitch)
+    uint32_t levelH;        // level | rows of the level << 8
+    uint32_t slotCap;       // candidate capacity of the cell | 1 << 31 when the reference skips the cell
+    uint32_t pad;
+};
+static_assert(sizeof(CellRecord) == 32, "one s_load_dwordx8 per cell");
+
 // Device pointers of one batched call. Passed to kernels by value.
 struct FrameSet {
     const uint8_t* img;     // level 0: caller's frames
     long long imgRowStride, imgFrameStride;
     uint8_t* pyr;           // levels >= 1
     int32_t* cellCount;     // [frame][totalCells]
+    const CellRecord* cells;  // [totalCells] of the current image size (the same for every frame)
     uint32_t* slots;        // [frame][totalSlots] packed candidates, grouped per cell
     uint32_t* cand;         // [frame][totalSlots] candidates of a level gathered in reference order
     uint16_t* nid;          // [frame][totalSlots] quadtree node of each candidate
@@ -136,6 +152,8 @@ struct ScaleTables {
 };
 void build_scale_tables(int nfeatures, float scaleFactor, int nlevels, ScaleTables& t);
 bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g, std::string& err);
+// The FAST cells of a geometry in the order of a frame's cell arrays; false if a field does not fit its record.
+bool build_cell_table(const PyramidGeom& g, std::vector<CellRecord>& cells);
 struct HostResizeTab {
     std::vector<int32_t> xofs, yofs;
     std::vector<int16_t> ialpha, ibeta;

@@ -74,6 +74,39 @@ void build_scale_tables(int nfeatures, float scaleFactor, int nlevels, ScaleTabl
 
 // Level sizes (src/ORBextractor.cc:1103-1104), FAST cell grid (:765-779) and quadtree roots
 // (:535-537) for one image size, plus where each level's data lives inside a frame's buffers.
+// Cell rectangles of ORBextractor::ComputeKeyPointsOctTree (src/ORBextractor.cc:783-798): cell (i, j) of a level starts at
+// minBorder + (i * hCell, j * wCell), is wCell + 6 by hCell + 6 pixels and is cut at the level's far borders; the
+// reference skips a cell that starts within 3 rows (6 columns) of them.
+bool build_cell_table(const PyramidGeom& g, std::vector<CellRecord>& cells) {
+    cells.assign((size_t)std::max(g.totalCells, 0), CellRecord{});
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom& L = g.lv[l];
+        const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+        for (int ci = 0; ci < L.nRows; ci++)
+            for (int cj = 0; cj < L.nCols; cj++) {
+                const int c = ci * L.nCols + cj;
+                const int iniX = kBorder + cj * L.wCell, iniY = kBorder + ci * L.hCell;
+                const int maxX = std::min(iniX + L.wCell + 6, maxBX), maxY = std::min(iniY + L.hCell + 6, maxBY);
+                const int sw = maxX - iniX - 6, sh = maxY - iniY - 6;
+                const bool empty = iniY >= maxBY - 3 || iniX >= maxBX - 6 || sw <= 0 || sh <= 0;
+                const long long slotOff = L.slotBase + (long long)c * L.slotCap;
+                if (L.cellBase + c >= g.totalCells || iniX > 0xFFFF || iniY > 0xFFFF || slotOff > 0x7FFFFFFFll ||
+                    L.offset > 0x7FFFFFFFll || L.h > 0xFFFFFF || L.slotCap > 0xFFFF)
+                    return false;
+                CellRecord& r = cells[(size_t)L.cellBase + c];
+                r.ini = (uint32_t)iniX | (uint32_t)iniY << 16;
+                // an empty cell's far corner may lie left of or above its first one: it is never looked at
+                r.max = empty ? r.ini : ((uint32_t)maxX | (uint32_t)maxY << 16);
+                r.slotOff = (uint32_t)slotOff;
+                r.levelOff = l ? (uint32_t)L.offset : 0u;
+                r.stride = l ? (uint32_t)L.stride : 0u;
+                r.levelH = (uint32_t)l | (uint32_t)L.h << 8;
+                r.slotCap = (uint32_t)L.slotCap | (empty ? 0x80000000u : 0u);
+            }
+    }
+    return true;
+}
+
 bool build_geometry(int width, int height, const ScaleTables& t, PyramidGeom& g, std::string& err) {
     const int nlevels = (int)t.scale.size();
     g = PyramidGeom();
