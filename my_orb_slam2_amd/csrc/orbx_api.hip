@@ -64,7 +64,7 @@ struct orbx_ctx {
     bool haveGeom = false;
     ResizeTab resize[ORBX_MAX_LEVELS];
     void* resizeBlob = nullptr;
-    void* cellBlob = nullptr;     // CellRecord[totalCells] of the current geometry
+    void* cellBlob = nullptr;     // CellRecord[totalCells], then uint32_t selLevel[totalSel], of the current geometry
     FusedPlan fused;              // grouped pyramid launches for this geometry (empty: one launch per level)
     void* fusedBlob = nullptr;
     // device buffers sized for max_width x max_height x max_batch
@@ -197,12 +197,21 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
             set_error("image %dx%d: a FAST cell does not fit its table record", w, h);
             return ORBX_ERR_INVALID;
         }
+        // behind the cells: the level of every entry of a frame's selected-keypoint regions (the descriptor kernel's
+        // waves are numbered by entry)
+        std::vector<uint32_t> selLevel((size_t)std::max(g.totalSel, 0), 0u);
+        for (int l = 0; l < g.nlevels; l++)
+            for (int i = g.lv[l].selBase; i < g.totalSel; i++) selLevel[(size_t)i] = (uint32_t)l;
         if (c->cellBlob) HIP_TRY(hipFree(c->cellBlob));
         c->cellBlob = nullptr;
         c->fs.cells = nullptr;
-        HIP_TRY(hipMalloc(&c->cellBlob, std::max<size_t>(cells.size(), 1) * sizeof(CellRecord)));
-        if (!cells.empty()) HIP_TRY(hipMemcpy(c->cellBlob, cells.data(), cells.size() * sizeof(CellRecord), hipMemcpyHostToDevice));
+        c->fs.selLevel = nullptr;
+        const size_t cellBytes = cells.size() * sizeof(CellRecord), selBytes = selLevel.size() * sizeof(uint32_t);
+        HIP_TRY(hipMalloc(&c->cellBlob, std::max<size_t>(cellBytes + selBytes, 64)));
+        if (cellBytes) HIP_TRY(hipMemcpy(c->cellBlob, cells.data(), cellBytes, hipMemcpyHostToDevice));
+        if (selBytes) HIP_TRY(hipMemcpy(static_cast<uint8_t*>(c->cellBlob) + cellBytes, selLevel.data(), selBytes, hipMemcpyHostToDevice));
         c->fs.cells = static_cast<const CellRecord*>(c->cellBlob);
+        c->fs.selLevel = reinterpret_cast<const uint32_t*>(static_cast<uint8_t*>(c->cellBlob) + cellBytes);
     }
     // grouped pyramid launches: range tables next to the resize tables
     if (c->fusedBlob) HIP_TRY(hipFree(c->fusedBlob));

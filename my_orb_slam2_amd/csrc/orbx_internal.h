@@ -78,6 +78,7 @@ struct FrameSet {
     uint8_t* pyr;           // levels >= 1
     int32_t* cellCount;     // [frame][totalCells]
     const CellRecord* cells;  // [totalCells] of the current image size (the same for every frame)
+    const uint32_t* selLevel; // [totalSel] pyramid level of every entry of a frame's selected-keypoint regions
     uint32_t* slots;        // [frame][totalSlots] packed candidates, grouped per cell
     uint32_t* cand;         // [frame][totalSlots] candidates of a level gathered in reference order
     uint16_t* nid;          // [frame][totalSlots] quadtree node of each candidate

@@ -371,8 +371,9 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
     // fetched together with the counts below (the slot exists even when it holds no keypoint), so the patch
     // loads wait for one round trip instead of two
     const uint32_t packed = fs.sel[(long long)f * g.totalSel + slot];
-    int l = 0;
-    while (l + 1 < g.nlevels && slot >= g.lv[l + 1].selBase) l++;
+    // the entry's level from the host-made table (one scalar load, issued together with the one above)
+    const int l = (int)*reinterpret_cast<const uint32_t __attribute__((address_space(4)))*>(
+        reinterpret_cast<uintptr_t>(fs.selLevel + slot));
     const int k = slot - g.lv[l].selBase;
     // Position in the frame's output: levels are concatenated in order (:1067-1096), so a keypoint sits behind
     // all keypoints of the lower levels. Batched calls read that number from sel_prefix_kernel's table (two
