@@ -211,6 +211,7 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
                 for (int q = 0; q < kBatch; q++) {
                     v[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, laneOff, min(rowOff, lastOff), 0);
                     rowOff += stepOff;
+                    asm("" : "+s"(rowOff));            // keep the running sum (one add per row, not a multiply per row)
                 }
 #pragma unroll
                 for (int q = 0; q < kBatch; q++)
