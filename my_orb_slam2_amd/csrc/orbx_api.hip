@@ -64,7 +64,7 @@ struct orbx_ctx {
     bool haveGeom = false;
     ResizeTab resize[ORBX_MAX_LEVELS];
     void* resizeBlob = nullptr;
-    void* cellBlob = nullptr;     // CellRecord[totalCells], then uint32_t selLevel[totalSel], of the current geometry
+    void* cellBlob = nullptr;     // CellRecord[totalCells], then SelRecord[totalSel], of the current geometry
     FusedPlan fused;              // grouped pyramid launches for this geometry (empty: one launch per level)
     void* fusedBlob = nullptr;
     // device buffers sized for max_width x max_height x max_batch
@@ -197,21 +197,35 @@ int ensure_geometry(orbx_ctx* c, int w, int h) {
             set_error("image %dx%d: a FAST cell does not fit its table record", w, h);
             return ORBX_ERR_INVALID;
         }
-        // behind the cells: the level of every entry of a frame's selected-keypoint regions (the descriptor kernel's
-        // waves are numbered by entry)
-        std::vector<uint32_t> selLevel((size_t)std::max(g.totalSel, 0), 0u);
-        for (int l = 0; l < g.nlevels; l++)
-            for (int i = g.lv[l].selBase; i < g.totalSel; i++) selLevel[(size_t)i] = (uint32_t)l;
+        // behind the cells: level and level geometry of every entry of a frame's selected-keypoint regions (the
+        // descriptor kernel's waves are numbered by entry)
+        std::vector<SelRecord> selRec((size_t)std::max(g.totalSel, 0), SelRecord{});
+        for (int l = 0; l < g.nlevels; l++) {
+            const LevelGeom& L = g.lv[l];
+            if (L.offset > 0x7FFFFFFFll || L.w > 0xFFFF || L.h > 0xFFFF) {
+                set_error("image %dx%d: a level does not fit its table record", w, h);
+                return ORBX_ERR_INVALID;
+            }
+            for (int i = L.selBase; i < g.totalSel; i++) {
+                SelRecord& r = selRec[(size_t)i];
+                r.levelK = (uint32_t)l | (uint32_t)(i - L.selBase) << 8;
+                r.levelOff = l ? (uint32_t)L.offset : 0u;
+                r.stride = l ? (uint32_t)L.stride : 0u;
+                r.wh = (uint32_t)L.w | (uint32_t)L.h << 16;
+                r.scale = L.scale;
+                r.kpSize = L.kpSize;
+            }
+        }
         if (c->cellBlob) HIP_TRY(hipFree(c->cellBlob));
         c->cellBlob = nullptr;
         c->fs.cells = nullptr;
-        c->fs.selLevel = nullptr;
-        const size_t cellBytes = cells.size() * sizeof(CellRecord), selBytes = selLevel.size() * sizeof(uint32_t);
+        c->fs.selRec = nullptr;
+        const size_t cellBytes = cells.size() * sizeof(CellRecord), selBytes = selRec.size() * sizeof(SelRecord);
         HIP_TRY(hipMalloc(&c->cellBlob, std::max<size_t>(cellBytes + selBytes, 64)));
         if (cellBytes) HIP_TRY(hipMemcpy(c->cellBlob, cells.data(), cellBytes, hipMemcpyHostToDevice));
-        if (selBytes) HIP_TRY(hipMemcpy(static_cast<uint8_t*>(c->cellBlob) + cellBytes, selLevel.data(), selBytes, hipMemcpyHostToDevice));
+        if (selBytes) HIP_TRY(hipMemcpy(static_cast<uint8_t*>(c->cellBlob) + cellBytes, selRec.data(), selBytes, hipMemcpyHostToDevice));
         c->fs.cells = static_cast<const CellRecord*>(c->cellBlob);
-        c->fs.selLevel = reinterpret_cast<const uint32_t*>(static_cast<uint8_t*>(c->cellBlob) + cellBytes);
+        c->fs.selRec = reinterpret_cast<const SelRecord*>(static_cast<uint8_t*>(c->cellBlob) + cellBytes);
     }
     // grouped pyramid launches: range tables next to the resize tables
     if (c->fusedBlob) HIP_TRY(hipFree(c->fusedBlob));

@@ -71,6 +71,20 @@ struct CellRecord {
 };
 static_assert(sizeof(CellRecord) == 32, "one s_load_dwordx8 per cell");
 
+// One entry of a frame's selected-keypoint regions as the descriptor kernel needs it, made on the host once per image
+// size: which level the entry belongs to, its index there, and that level's geometry (one scalar 32-byte load per
+// wave instead of a walk over the level table followed by loads of the level's fields).
+struct SelRecord {
+    uint32_t levelK;        // level | index of the entry inside the level's region << 8
+    uint32_t levelOff;      // byte offset of the level inside a frame's pyramid buffer (levels >= 1)
+    uint32_t stride;        // row pitch of the level in bytes (levels >= 1)
+    uint32_t wh;            // level width | height << 16
+    float scale;            // mvScaleFactor[level]
+    float kpSize;           // keypoint size at that level
+    uint32_t pad[2];
+};
+static_assert(sizeof(SelRecord) == 32, "one s_load_dwordx8 per keypoint");
+
 // Device pointers of one batched call. Passed to kernels by value.
 struct FrameSet {
     const uint8_t* img;     // level 0: caller's frames
@@ -78,7 +92,7 @@ struct FrameSet {
     uint8_t* pyr;           // levels >= 1
     int32_t* cellCount;     // [frame][totalCells]
     const CellRecord* cells;  // [totalCells] of the current image size (the same for every frame)
-    const uint32_t* selLevel; // [totalSel] pyramid level of every entry of a frame's selected-keypoint regions
+    const SelRecord* selRec;  // [totalSel] level and level geometry of every entry of a frame's selected-keypoint regions
     uint32_t* slots;        // [frame][totalSlots] packed candidates, grouped per cell
     uint32_t* cand;         // [frame][totalSlots] candidates of a level gathered in reference order
     uint16_t* nid;          // [frame][totalSlots] quadtree node of each candidate

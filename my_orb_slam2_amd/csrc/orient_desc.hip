@@ -93,7 +93,6 @@ constexpr MomentWeights make_moment_weights() {
         }
     return m;
 }
-__device__ const MomentWeights c_momw = make_moment_weights();
 
 // Can the rounded, rotated pattern land on offset (dx, dy)? Its real position is within radius sqrt(338)
 // (the farthest pattern point is (-13,-13)); (dx, dy) is reachable if its unit box touches that disc.
@@ -224,7 +223,27 @@ constexpr ItemTables make_item_tables() {
 constexpr ItemTables kItems = make_item_tables();
 static_assert(kItems.nh <= kHIters * 64 && kItems.nv <= kVIters * 64, "work item tables overflow");
 static_assert(kItems.nh == kTItems && kItems.ok, "a work item points outside the stored part of T, or the slot tables miss an item");
-__device__ const ItemTables c_items = make_item_tables();
+// What a lane fetches before its keypoint's pixels arrive, 64 bytes per lane in one place (four 16-byte loads off one
+// base address): its work items of both blur passes and its intensity-centroid weights.
+struct LaneTable {
+    uint32_t w[64][16];     // per lane: h[0..2], v[0..2], two spare words, momw[0..3] as (.x, .y) pairs
+};
+constexpr LaneTable make_lane_table() {
+    LaneTable t{};
+    const ItemTables it = make_item_tables();
+    const MomentWeights mw = make_moment_weights();
+    for (int lane = 0; lane < 64; lane++) {
+        for (int q = 0; q < kHIters; q++) t.w[lane][q] = it.h[64 * q + lane];
+        for (int q = 0; q < kVIters; q++) t.w[lane][3 + q] = it.v[64 * q + lane];
+        for (int q = 0; q < 4; q++) {
+            t.w[lane][8 + 2 * q] = mw.w[q][lane][0];
+            t.w[lane][9 + 2 * q] = mw.w[q][lane][1];
+        }
+    }
+    return t;
+}
+static_assert(kHIters == 3 && kVIters == 3, "the lane table has three item words per pass");
+__device__ __attribute__((aligned(64))) const LaneTable c_lane = make_lane_table();
 
 
 __device__ __forceinline__ int reflect101(int p, int len) {
@@ -371,10 +390,13 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
     // fetched together with the counts below (the slot exists even when it holds no keypoint), so the patch
     // loads wait for one round trip instead of two
     const uint32_t packed = fs.sel[(long long)f * g.totalSel + slot];
-    // the entry's level from the host-made table (one scalar load, issued together with the one above)
-    const int l = (int)*reinterpret_cast<const uint32_t __attribute__((address_space(4)))*>(
-        reinterpret_cast<uintptr_t>(fs.selLevel + slot));
-    const int k = slot - g.lv[l].selBase;
+    // the entry's level, its index there and the level's geometry from the host-made table (one scalar load, issued
+    // together with the one above)
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    const u32x8 rec = *reinterpret_cast<const u32x8 __attribute__((address_space(4)))*>(
+        reinterpret_cast<uintptr_t>(fs.selRec + slot));
+    const int l = (int)(rec[0] & 0xFFu), k = (int)(rec[0] >> 8);
+    const int levelW = (int)(rec[3] & 0xFFFFu), levelH = (int)(rec[3] >> 16);
     // Position in the frame's output: levels are concatenated in order (:1067-1096), so a keypoint sits behind
     // all keypoints of the lower levels. Batched calls read that number from sel_prefix_kernel's table (two
     // loads); in a call of a few frames, where one more dependent launch costs more than some scalar work per
@@ -404,20 +426,21 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
     }
     const int outIdx = before + k;
     if (k >= mine || outIdx >= cap) return;
-    const LevelGeom& L = g.lv[l];
     uint8_t* R = s_mem + wv * kWaveLds;                                        // raw patch, later Bl
     uint8_t* Tb = R + kTOffset;                                                // packed row sums
     uint32_t* R32 = reinterpret_cast<uint32_t*>(R);
 
     // work items of both blur passes (independent of everything else: their latency hides behind the staging)
     uint32_t hItem[kHIters], vItem[kVIters];
-#pragma unroll
-    for (int q = 0; q < kHIters; q++) hItem[q] = c_items.h[64 * q + lane];
-#pragma unroll
-    for (int q = 0; q < kVIters; q++) vItem[q] = c_items.v[64 * q + lane];
     uint2 momw[4];                                 // this lane's intensity-centroid weights, fetched just as early
-#pragma unroll
-    for (int q = 0; q < 4; q++) momw[q] = reinterpret_cast<const uint2*>(&c_momw.w[0][0][0])[64 * q + lane];
+    {
+        const uint4* lt = reinterpret_cast<const uint4*>(&c_lane.w[lane][0]);
+        const uint4 a = lt[0], b = lt[1], c2 = lt[2], d = lt[3];
+        hItem[0] = a.x, hItem[1] = a.y, hItem[2] = a.z;
+        vItem[0] = a.w, vItem[1] = b.x, vItem[2] = b.y;
+        momw[0] = make_uint2(c2.x, c2.y), momw[1] = make_uint2(c2.z, c2.w);
+        momw[2] = make_uint2(d.x, d.y), momw[3] = make_uint2(d.z, d.w);
+    }
 
     const int kx = cand_x(packed) + kBorder;   // level coordinates (:835-836)
     const int ky = cand_y(packed) + kBorder;
@@ -427,24 +450,24 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
         img = fs.img + (long long)f * fs.imgFrameStride;
         rowStride = (int)fs.imgRowStride;
     } else {
-        img = fs.pyr + (long long)f * g.pyrBytes + L.offset;
-        rowStride = L.stride;
+        img = fs.pyr + (long long)f * g.pyrBytes + rec[1];
+        rowStride = (int)rec[2];
     }
     // ---- stage the raw patch: LDS column j <-> image column kx-23+j, LDS row r <-> image row ky-21+r ----
     // Columns kx-21 .. kx+21 are used. When they all lie inside the level the rows come in as dwords: lane
     // (row slot, dword d) reads the two aligned dwords around its four bytes; dwords that stick out of the
     // row are clamped into it (they only hold unused columns). Rows outside the level are reflected.
-    if (kx - kPR >= 0 && kx + kPR < L.w) {
+    if (kx - kPR >= 0 && kx + kPR < levelW) {
         const int xa = (kx - kCx) & ~3;
         const uint32_t shift = (uint32_t)((kx - kCx) & 3);
         const int d = lane & 15, rs = lane >> 4;
         const int colLo = min(max(xa + 4 * d, 0), rowStride - 4), colHi = min(max(xa + 4 * d + 4, 0), rowStride - 4);
-        const bool rowsInside = ky - kPR >= 0 && ky - kPR + kRowsAlloc <= L.h;
+        const bool rowsInside = ky - kPR >= 0 && ky - kPR + kRowsAlloc <= levelH;
         uint32_t lo[kRowsAlloc / 4], hi[kRowsAlloc / 4];
         // Rows come through a buffer resource over the level: the row offset is scalar, the two dword offsets are
         // this lane's constants, so a load needs no address arithmetic (and cannot fault).
         const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, L.h * rowStride, 0x00027000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, levelH * rowStride, 0x00027000);
         if (rowsInside) {
             const int offLo = rs * rowStride + colLo, offHi = rs * rowStride + colHi;
             const int row0 = (ky - kPR) * rowStride;                         // wave-uniform
@@ -456,7 +479,7 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
         } else {
 #pragma unroll
             for (int q = 0; q < kRowsAlloc / 4; q++) {
-                const int sy = reflect101(ky - kPR + rs + 4 * q, L.h);
+                const int sy = reflect101(ky - kPR + rs + 4 * q, levelH);
                 lo[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, sy * rowStride + colLo, 0, 0);
                 hi[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, sy * rowStride + colHi, 0, 0);
             }
@@ -471,7 +494,7 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
         // BORDER_REFLECT_101 coordinates
         for (int i = lane; i < kRowsAlloc * kRPitch; i += 64) {
             const int r = i / kRPitch, c = i - r * kRPitch;
-            const int sy = reflect101(ky - kPR + r, L.h), sx = reflect101(kx - kCx + c, L.w);
+            const int sy = reflect101(ky - kPR + r, levelH), sx = reflect101(kx - kCx + c, levelW);
             R[i] = img[(long long)sy * rowStride + sx];
         }
     }
@@ -590,9 +613,9 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
     if (lane == 0) {
         orbx_keypoint kp;
         // coordinates are scaled after the descriptors, and only above level 0 (:1087-1093)
-        kp.x = l ? __fmul_rn((float)kx, L.scale) : (float)kx;
-        kp.y = l ? __fmul_rn((float)ky, L.scale) : (float)ky;
-        kp.size = L.kpSize;
+        kp.x = l ? __fmul_rn((float)kx, __uint_as_float(rec[4])) : (float)kx;
+        kp.y = l ? __fmul_rn((float)ky, __uint_as_float(rec[4])) : (float)ky;
+        kp.size = __uint_as_float(rec[5]);
         kp.angle = angle;
         kp.response = (float)cand_score(packed);
         kp.octave = l;
