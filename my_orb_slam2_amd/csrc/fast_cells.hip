@@ -15,8 +15,6 @@
 //      score (cv cornerScore) is S - 1; corners keep their S in an LDS score map;
 //   4. corners that beat their 8 neighbours strictly are written in row-major order to the cell's
 //      slot array.
-#include <cstdlib>
-
 #include "orbx_internal.h"
 
 namespace orbx {
@@ -370,8 +368,7 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
 hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nframes, int iniTh, int minTh,
                              hipStream_t s) {
     if (g.totalCells == 0) return hipSuccess;
-    static const int wavesEnv = getenv("ORBX_FAST_WAVES") ? atoi(getenv("ORBX_FAST_WAVES")) : 0;
-    const int waves = wavesEnv == 1 || wavesEnv == 2 ? wavesEnv : kDefaultCellsPerBlock;
+    constexpr int waves = kDefaultCellsPerBlock;
     const int ldsPerWave = (g.maxTileBytes + g.maxScoreBytes + 2 * g.maxScanPix + 16 + 15) & ~15;
     const size_t lds = (size_t)ldsPerWave * waves;
     dim3 grid(nframes, (g.totalCells + waves - 1) / waves, 1), block(64 * waves, 1, 1);
@@ -388,9 +385,7 @@ hipError_t launch_fast_cells(const FrameSet& fs, const PyramidGeom& g, int nfram
         hipLaunchKernelGGL(kernel, grid, block, lds, s, fs, g, iniTh, minTh, ldsPerWave);
         return hipGetLastError();
     };
-    if (waves == 1) return tp == 40 ? launch(fast_cells_kernel<40, 1>) : tp == 48 ? launch(fast_cells_kernel<48, 1>) : launch(fast_cells_kernel<80, 1>);
-    if (waves == 2) return tp == 40 ? launch(fast_cells_kernel<40, 2>) : tp == 48 ? launch(fast_cells_kernel<48, 2>) : launch(fast_cells_kernel<80, 2>);
-    return tp == 40 ? launch(fast_cells_kernel<40, 4>) : tp == 48 ? launch(fast_cells_kernel<48, 4>) : launch(fast_cells_kernel<80, 4>);
+    return tp == 40 ? launch(fast_cells_kernel<40, waves>) : tp == 48 ? launch(fast_cells_kernel<48, waves>) : launch(fast_cells_kernel<80, waves>);
 }
 
 }  // namespace orbx
