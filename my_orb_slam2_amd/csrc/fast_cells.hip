@@ -22,64 +22,96 @@ namespace orbx {
 namespace {
 
 // Three-input minimum / maximum of both 16-bit halves at once (gfx950's packed half-float forms). The halves hold
-// 0x6400 | n, the half-float 1024 + n, for n in 0..255: consecutive integers there, so these are exact integer
-// minima and maxima.
+// a pixel value 0..255 as it is: as half-floats these are zero and the 255 smallest subnormals, which compare like
+// the integers (kernels run with half-float subnormals kept), so these are exact integer minima and maxima.
+// SWAP = 0: the operands as they are; 1: the third with its halves exchanged; 2: the second and the third (the
+// operand-select bits of the packed encoding, no extra instruction).
+template <int SWAP>
 __device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
-    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    if (SWAP == 0) asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if (SWAP == 1) asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+template <int SWAP>
 __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    if (SWAP == 0) asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else if (SWAP == 1) asm("v_pk_maximum3_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_maximum3_f16 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
-// Corner strength of the pixel at p (LDS, row pitch `pitch`): see step 3 above.
-// With d_k = v - c_k: max over arcs of min(d) = v - min over arcs of max(c), and min over arcs of max(d) =
-// v - max over arcs of min(c), so the sixteen differences are never formed; and an arc's maximum of c is 255 minus
-// its minimum of 255 - c, so one network of minima over the pairs (c, 255 - c), one pair per dword, serves both
-// polarities. The arcs k..k+8 and k+1..k+9 (k even) share the eight positions k+1..k+8, and
-// max(min(core, c_k), min(core, c_k+9)) = min(core, max(c_k, c_k+9)): eight pair minima, eight such maxima, two
-// three-input minima per even k and four three-input maxima give (largest arc minimum, 255 - smallest arc maximum).
+// Smallest (MIN) or largest value of every run of nine consecutive circle positions, all sixteen runs at once.
+// w[j] holds positions j (low half) and j + 8 (high half); with x[j] = w[j] for j < 8 and w[j - 8] with its halves
+// exchanged for j >= 8, x[j] holds positions j and j + 8 for every j mod 16, and the run that starts at k (low
+// half) and the one that starts at k + 8 (high half) are the reduction of x[k] .. x[k+8]: three reductions of
+// three neighbours, t[k], t[k+3], t[k+6], where t[j + 8] is again t[j] with its halves exchanged. Sixteen
+// three-input instructions for the sixteen runs.
+template <bool MIN>
+__device__ __forceinline__ void arc_runs(const uint32_t (&w)[8], uint32_t (&run)[8]) {
+    auto op0 = [](uint32_t a, uint32_t b, uint32_t c) { return MIN ? pk_min3<0>(a, b, c) : pk_max3<0>(a, b, c); };
+    auto op1 = [](uint32_t a, uint32_t b, uint32_t c) { return MIN ? pk_min3<1>(a, b, c) : pk_max3<1>(a, b, c); };
+    auto op2 = [](uint32_t a, uint32_t b, uint32_t c) { return MIN ? pk_min3<2>(a, b, c) : pk_max3<2>(a, b, c); };
+    uint32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 6; j++) t[j] = op0(w[j], w[j + 1], w[j + 2]);
+    t[6] = op1(w[6], w[7], w[0]);
+    t[7] = op2(w[7], w[0], w[1]);
+    run[0] = op0(t[0], t[3], t[6]);
+    run[1] = op0(t[1], t[4], t[7]);
+    run[2] = op1(t[2], t[5], t[0]);
+    run[3] = op1(t[3], t[6], t[1]);
+    run[4] = op1(t[4], t[7], t[2]);
+    run[5] = op2(t[5], t[0], t[3]);
+    run[6] = op2(t[6], t[1], t[4]);
+    run[7] = op2(t[7], t[2], t[5]);
+}
+
+// Corner strength of the pixel whose scan offset is e; `at` is the LDS byte address of the tile plus e, so the
+// pixel sits at at + 3 * pitch + 4 and the circle at constant offsets from there: see step 3 above.
+// With d_k = v - c_k: max over runs of min(d) = v - min over runs of max(c), and min over runs of max(d) =
+// v - max over runs of min(c), so the sixteen differences are never formed. Position k comes in through a byte
+// load (the low half of a register), position k + 8 through the load that fills the high half of one (on this chip
+// such a load clears the other half instead of keeping it, so the two cannot share a register: one OR per pair
+// joins them), and the packed network above starts from there.
 template <int pitch>
-__device__ __forceinline__ int corner_strength(const uint8_t* p) {
-    const int v = p[0];
-    int c[16];
-    c[0] = p[3 * pitch];
-    c[1] = p[3 * pitch + 1];
-    c[2] = p[2 * pitch + 2];
-    c[3] = p[pitch + 3];
-    c[4] = p[3];
-    c[5] = p[-pitch + 3];
-    c[6] = p[-2 * pitch + 2];
-    c[7] = p[-3 * pitch + 1];
-    c[8] = p[-3 * pitch];
-    c[9] = p[-3 * pitch - 1];
-    c[10] = p[-2 * pitch - 2];
-    c[11] = p[-pitch - 3];
-    c[12] = p[-3];
-    c[13] = p[pitch - 3];
-    c[14] = p[2 * pitch - 2];
-    c[15] = p[3 * pitch - 1];
-    // low half 0x6400 + c, high half 0x6400 + 255 - c: 0x64FF6400 + c - (c << 16), one 24-bit multiply-add
-    const int kHalves = 0x64FF6400, kSpread = -0xFFFF;
-    uint32_t w[16];
+__device__ __forceinline__ int corner_strength(uint32_t at) {
+    constexpr int c0 = 3 * pitch + 4;      // the pixel itself
+    uint32_t w[8], h[8], v;
+    asm volatile(
+        "ds_read_u8 %0, %17 offset:%18\n\tds_read_u8_d16_hi %8, %17 offset:%26\n\t"
+        "ds_read_u8 %1, %17 offset:%19\n\tds_read_u8_d16_hi %9, %17 offset:%27\n\t"
+        "ds_read_u8 %2, %17 offset:%20\n\tds_read_u8_d16_hi %10, %17 offset:%28\n\t"
+        "ds_read_u8 %3, %17 offset:%21\n\tds_read_u8_d16_hi %11, %17 offset:%29\n\t"
+        "ds_read_u8 %4, %17 offset:%22\n\tds_read_u8_d16_hi %12, %17 offset:%30\n\t"
+        "ds_read_u8 %5, %17 offset:%23\n\tds_read_u8_d16_hi %13, %17 offset:%31\n\t"
+        "ds_read_u8 %6, %17 offset:%24\n\tds_read_u8_d16_hi %14, %17 offset:%32\n\t"
+        "ds_read_u8 %7, %17 offset:%25\n\tds_read_u8_d16_hi %15, %17 offset:%33\n\t"
+        "ds_read_u8 %16, %17 offset:%34\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]),
+          "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]), "=&v"(h[7]), "=&v"(v)
+        : "v"(at),
+          // positions 0..7: (0,3) (1,3) (2,2) (3,1) (3,0) (3,-1) (2,-2) (1,-3)
+          "i"(c0 + 3 * pitch), "i"(c0 + 3 * pitch + 1), "i"(c0 + 2 * pitch + 2), "i"(c0 + pitch + 3), "i"(c0 + 3),
+          "i"(c0 - pitch + 3), "i"(c0 - 2 * pitch + 2), "i"(c0 - 3 * pitch + 1),
+          // positions 8..15: (0,-3) (-1,-3) (-2,-2) (-3,-1) (-3,0) (-3,1) (-2,2) (-1,3)
+          "i"(c0 - 3 * pitch), "i"(c0 - 3 * pitch - 1), "i"(c0 - 2 * pitch - 2), "i"(c0 - pitch - 3), "i"(c0 - 3),
+          "i"(c0 + pitch - 3), "i"(c0 + 2 * pitch - 2), "i"(c0 + 3 * pitch - 1),
+          "i"(c0)
+        : "memory");
 #pragma unroll
-    for (int k = 0; k < 16; k++) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(w[k]) : "v"(c[k]), "s"(kSpread), "v"(kHalves));
-    uint32_t pr[8], ends[8], r[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        pr[i] = pk_min3(w[2 * i + 1], w[(2 * i + 2) & 15], w[(2 * i + 2) & 15]);     // positions 2i+1, 2i+2
-        ends[i] = pk_max3(w[2 * i], w[(2 * i + 9) & 15], w[(2 * i + 9) & 15]);       // the two ends around core 2i
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        r[i] = pk_min3(pk_min3(pr[i], pr[(i + 1) & 7], pr[(i + 2) & 7]), pr[(i + 3) & 7], ends[i]);
-    const uint32_t best = pk_max3(pk_max3(r[0], r[1], r[2]), pk_max3(r[3], r[4], r[5]), pk_max3(r[6], r[7], r[7]));
-    const int loMax = (int)(best & 0xFFFFu) - 0x6400;          // largest arc minimum
-    const int hiMin = 255 + 0x6400 - (int)(best >> 16);        // smallest arc maximum
-    return max(v - hiMin, loMax - v);      // darker-arc strength, brighter-arc strength
+    for (int j = 0; j < 8; j++) w[j] |= h[j];
+    uint32_t lo[8], hi[8];
+    arc_runs<true>(w, lo);        // smallest value of every run
+    arc_runs<false>(w, hi);       // largest value of every run
+    const uint32_t loBest = pk_max3<0>(pk_max3<0>(lo[0], lo[1], lo[2]), pk_max3<0>(lo[3], lo[4], lo[5]), pk_max3<0>(lo[6], lo[7], lo[7]));
+    const uint32_t hiBest = pk_min3<0>(pk_min3<0>(hi[0], hi[1], hi[2]), pk_min3<0>(hi[3], hi[4], hi[5]), pk_min3<0>(hi[6], hi[7], hi[7]));
+    const int loMax = (int)max(loBest & 0xFFFFu, loBest >> 16);     // largest run minimum
+    const int hiMin = (int)min(hiBest & 0xFFFFu, hiBest >> 16);     // smallest run maximum
+    return max((int)v - hiMin, loMax - (int)v);      // darker-run strength, brighter-run strength
 }
 
 // Unsigned 16-bit operations on both halves of a dword.
@@ -174,9 +206,10 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
 
     // ---- 1. stage the cell in LDS ----
     uint8_t* tile = smem;
+    // the tile's LDS byte address (xo = 1: scan offset e is tile byte e + 3 * PITCH + 4)
+    const uint32_t tileAt = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)tile;
     // Tile column c holds image column iniX - 1 + c, so the first scanned pixel (iniX + 3) sits at tile column 4
     // and groups of four scanned pixels are whole LDS dwords.
-    constexpr int xo = 1;
     {
         const int xa = (iniX - 1) & ~3;
         const uint32_t shift = (uint32_t)((iniX - 1) & 3);
@@ -318,15 +351,15 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     int nc = 0;
     for (int base = 0; base < nq; base += 64) {
         const int qi = base + lane;
-        int e = 0, S = 0;
-        if (qi < nq) {
-            e = queue[qi];
-            S = corner_strength<PITCH>(tile + 3 * PITCH + xo + 3 + e);
-            if (S > tcur) score[PITCH + 1 + e] = (uint8_t)S; else S = 0;
-        }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(S > 0);
+        // lanes past the end of the queue repeat its last entry and drop out at the comparison: no branch around
+        // the network, and the lane mask of the corners comes straight from two compares
+        const int e = queue[min(qi, nq - 1)];
+        const int S = corner_strength<PITCH>(tileAt + (uint32_t)e);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(S > tcur) & __builtin_amdgcn_ballot_w64(qi < nq);
+        const bool corner = __builtin_amdgcn_inverse_ballot_w64(m);
+        if (corner) score[PITCH + 1 + e] = (uint8_t)S;
         // in-place compaction: position nc+prefix <= qi, and every lane has read queue[qi] above
-        if (S > 0) queue[nc + prefix_count(m)] = (uint16_t)e;
+        if (corner) queue[nc + prefix_count(m)] = (uint16_t)e;
         nc += __popcll(m);
     }
     wave_sync();
@@ -334,20 +367,16 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
     // ---- 4. suppression + ordered output ----
     for (int base = 0; base < nc; base += 64) {
         const int qi = base + lane;
-        bool keep = false;
-        int e = 0, sc = 0;
-        if (qi < nc) {
-            e = queue[qi];
-            constexpr int sp = PITCH;
-            const uint8_t* s = score + PITCH + 1 + e;
-            sc = s[0] - 1;                           // every queued pixel is a corner at this threshold
-            const int a0 = s[-sp - 1], a1 = s[-sp], a2 = s[-sp + 1], a3 = s[-1], a4 = s[1], a5 = s[sp - 1], a6 = s[sp],
-                      a7 = s[sp + 1];
-            const int nb = max(max(max(a0, a1), max(a2, a3)), max(max(a4, a5), max(a6, a7)));
-            // the map holds S only for corners (S > threshold); everything else counts as score 0
-            keep = sc > max(nb - 1, 0);
-        }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        const int e = queue[min(qi, nc - 1)];       // lanes past the end: as above
+        constexpr int sp = PITCH;
+        const uint8_t* s = score + PITCH + 1 + e;
+        const int sc = s[0] - 1;                     // every queued pixel is a corner at this threshold
+        const int a0 = s[-sp - 1], a1 = s[-sp], a2 = s[-sp + 1], a3 = s[-1], a4 = s[1], a5 = s[sp - 1], a6 = s[sp],
+                  a7 = s[sp + 1];
+        const int nb = max(max(max(a0, a1), max(a2, a3)), max(max(a4, a5), max(a6, a7)));
+        // the map holds S only for corners (S > threshold); everything else counts as score 0
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(sc > max(nb - 1, 0)) & __builtin_amdgcn_ballot_w64(qi < nc);
+        const bool keep = __builtin_amdgcn_inverse_ballot_w64(m);
         if (keep) {
             const int pos = nout + prefix_count(m);
             // e = y * PITCH + x with e < 2^13: the quotient by a 20-bit reciprocal is exact (the error of the rounded-up

@@ -322,12 +322,11 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// min(255, v >> 16) of four 16.16 sums (each below 2^31) as four bytes: the high halves of two sums are paired
-// by v_perm_b32 and v_sat_pk_u8_i16 saturates and packs a pair.
-__device__ __forceinline__ uint32_t pack4_sat(const uint4& v) {
-    uint32_t lo, hi;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(lo) : "v"(__builtin_amdgcn_perm(v.y, v.x, 0x07060302u)));
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(hi) : "v"(__builtin_amdgcn_perm(v.w, v.z, 0x07060302u)));
+// The top bytes of four 32-bit sums as four bytes (three v_perm_b32). The column pass keeps its sums shifted
+// left by 8 and accumulates with saturation, so a sum's top byte is min(255, sum >> 16) of the unshifted sum.
+__device__ __forceinline__ uint32_t pack4_top(const uint4& v) {
+    const uint32_t lo = __builtin_amdgcn_perm(v.y, v.x, 0x0c0c0703u);     // bytes 0, 1
+    const uint32_t hi = __builtin_amdgcn_perm(v.w, v.z, 0x0c0c0703u);
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);   // low halves of lo and hi
 }
 
@@ -547,30 +546,34 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
 
     // ---- column pass: Bl[y][j] = min(255, (sum_r K[r] * T[y+r][j] + 32768) >> 16), y = patch row - 3 ----
     {
-        const uint32_t k2 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 49u : 48u, k3 = blurTaps == ORBX_BLUR_CV_4_0_0 ? 55u : 56u;
-        const uint32_t we[4] = {18u | (34u << 16), k2 | (k3 << 16), k2 | (34u << 16), 18u};
-        const uint32_t wo[4] = {18u << 16, 34u | (k2 << 16), k3 | (k2 << 16), 34u | (18u << 16)};
+        // Taps and rounding constant times 256: a 16.16 sum of at least 256.0 then no longer fits 32 bits, and the
+        // saturating form of v_dot2_u32_u16 stops at 0xFFFFFFFF, so bits 24..31 of the result are min(255, sum >> 16)
+        // (the partial sums only grow, so a sum that fits never saturates on the way).
+        const uint32_t k0 = 18u << 8, k1 = 34u << 8, k2 = (blurTaps == ORBX_BLUR_CV_4_0_0 ? 49u : 48u) << 8,
+                       k3 = (blurTaps == ORBX_BLUR_CV_4_0_0 ? 55u : 56u) << 8;
+        const uint32_t we[4] = {k0 | (k1 << 16), k2 | (k3 << 16), k2 | (k1 << 16), k0};
+        const uint32_t wo[4] = {k0 << 16, k1 | (k2 << 16), k3 | (k2 << 16), k1 | (k0 << 16)};
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int q = 0; q < kVIters; q++) {
             const uint8_t* tp = Tb + (vItem[q] & 0xFFFFu);
-            uint4 e = make_uint4(32768u, 32768u, 32768u, 32768u), o = e;
+            uint4 e = make_uint4(32768u << 8, 32768u << 8, 32768u << 8, 32768u << 8), o = e;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const uint4 t = *reinterpret_cast<const uint4*>(tp + r * 16);
                 const us2 a = __builtin_bit_cast(us2, we[r]), b = __builtin_bit_cast(us2, wo[r]);
-                e.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), a, e.x, false);
-                e.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), a, e.y, false);
-                e.z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.z), a, e.z, false);
-                e.w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.w), a, e.w, false);
-                o.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), b, o.x, false);
-                o.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), b, o.y, false);
-                o.z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.z), b, o.z, false);
-                o.w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.w), b, o.w, false);
+                e.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), a, e.x, true);
+                e.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), a, e.y, true);
+                e.z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.z), a, e.z, true);
+                e.w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.w), a, e.w, true);
+                o.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), b, o.x, true);
+                o.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), b, o.y, true);
+                o.z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.z), b, o.z, true);
+                o.w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.w), b, o.w, true);
             }
             uint32_t* bl = reinterpret_cast<uint32_t*>(R + (vItem[q] >> 16));
-            bl[0] = pack4_sat(e);
-            bl[kTPitch / 4] = pack4_sat(o);
+            bl[0] = pack4_top(e);
+            bl[kTPitch / 4] = pack4_top(o);
         }
     }
     wave_sync();
