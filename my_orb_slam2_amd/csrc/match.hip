@@ -40,6 +40,28 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Smallest of a tile's sixteen accumulators: seven v_min3_f32 and one v_min_f32, written out. fminf() would first
+// pass an operand through v_max_f32(x, x) to quiet a signalling NaN, and the accumulators only ever hold small
+// integers. The block begins with the wait states a vector instruction needs before it may read what a matrix
+// instruction wrote (the assembler does not insert them for text it cannot see into; twelve is what the compiler
+// places before its own first read of such a result).
+__device__ __forceinline__ float min16f(const v16f& a) {
+    float t0, t1, t2;
+    asm("s_nop 11\n\t"
+        "v_min3_f32 %0, %3, %4, %5\n\t"
+        "v_min3_f32 %1, %6, %7, %8\n\t"
+        "v_min3_f32 %2, %9, %10, %11\n\t"
+        "v_min3_f32 %0, %0, %1, %12\n\t"
+        "v_min3_f32 %1, %13, %14, %15\n\t"
+        "v_min3_f32 %2, %2, %16, %17\n\t"
+        "v_min3_f32 %0, %0, %1, %2\n\t"
+        "v_min_f32 %0, %0, %18"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+          "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
+    return t0;
+}
+
 }  // namespace
 
 // One wave owns 32 * NQB queries and walks the chunk's rows 32 at a time.
@@ -117,10 +139,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 2) void knn2_kernel(const uint
                 // without block scales (every block scale 1)
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc, 4, 4, 0, 0, 0, 0);
             }
-            const float m0 = fminf(fminf(acc[0], acc[1]), acc[2]), m1 = fminf(fminf(acc[3], acc[4]), acc[5]);
-            const float m2 = fminf(fminf(acc[6], acc[7]), acc[8]), m3 = fminf(fminf(acc[9], acc[10]), acc[11]);
-            const float m4 = fminf(fminf(acc[12], acc[13]), acc[14]);
-            const float mn = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), acc[15]));
+            const float mn = min16f(acc);
             // A row can only change the best two if its distance is below the current second best (a lane meets its
             // rows in ascending order, so a later row carries a larger key than any key it holds).
             const unsigned long long hit = __builtin_amdgcn_ballot_w64(mn < thr[b]);
