@@ -143,6 +143,22 @@ def test_descriptor_bits_against_libm_float_trig():
     assert rate < 1e-4
 
 
+def test_black_and_white_blocks_saturate_the_blur():
+    """Blocks of 0 and 255: the 4.0.0 taps sum to 257, so the blur of a white area overshoots 255.0 and is clamped
+    (min(255, sum >> 16)); FAST meets its extreme pixel values and strengths of 254."""
+    rng = np.random.default_rng(5)
+    img = np.zeros((480, 752), np.uint8)
+    for _ in range(500):
+        x, y = int(rng.integers(0, 740)), int(rng.integers(0, 470))
+        w, h = int(rng.integers(8, 60)), int(rng.integers(8, 60))
+        img[y:y + h, x:x + w] = 255 if rng.integers(0, 2) else 0
+    gpu, cpu = make()
+    assert compare_frame(gpu, cpu, img) > 600
+    taps = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    assert ((taps.sum() * 255) * taps.sum() + 32768) >> 16 > 255      # the unclamped value of an all-white window
+    assert (cpu.level_blurred(0) == 255).any() and (cpu.level_candidates(0)["response"] == 254).any()
+
+
 def test_blur_variant_4_2():
     gpu, cpu = make(blur=m.BLUR_CV_4_2_PLUS)
     compare_frame(gpu, cpu, m.synth_frame(7))
