@@ -72,23 +72,23 @@ __device__ __forceinline__ void arc_runs(const uint32_t (&w)[8], uint32_t (&run)
 // Corner strength of the pixel whose scan offset is e; `at` is the LDS byte address of the tile plus e, so the
 // pixel sits at at + 3 * pitch + 4 and the circle at constant offsets from there: see step 3 above.
 // With d_k = v - c_k: max over runs of min(d) = v - min over runs of max(c), and min over runs of max(d) =
-// v - max over runs of min(c), so the sixteen differences are never formed. Position k comes in through a byte
-// load (the low half of a register), position k + 8 through the load that fills the high half of one (on this chip
-// such a load clears the other half instead of keeping it, so the two cannot share a register: one OR per pair
-// joins them), and the packed network above starts from there.
+// v - max over runs of min(c), so the sixteen differences are never formed. The sixteen circle bytes come in through
+// sixteen byte loads at constant offsets; one v_lshl_or_b32 per pair puts position k + 8 above position k, and the
+// packed network above starts from there. (The loads that fill only one half of a register would save nothing:
+// on this chip they clear the other half, so two of them cannot share a destination.)
 template <int pitch>
 __device__ __forceinline__ int corner_strength(uint32_t at) {
     constexpr int c0 = 3 * pitch + 4;      // the pixel itself
     uint32_t w[8], h[8], v;
     asm volatile(
-        "ds_read_u8 %0, %17 offset:%18\n\tds_read_u8_d16_hi %8, %17 offset:%26\n\t"
-        "ds_read_u8 %1, %17 offset:%19\n\tds_read_u8_d16_hi %9, %17 offset:%27\n\t"
-        "ds_read_u8 %2, %17 offset:%20\n\tds_read_u8_d16_hi %10, %17 offset:%28\n\t"
-        "ds_read_u8 %3, %17 offset:%21\n\tds_read_u8_d16_hi %11, %17 offset:%29\n\t"
-        "ds_read_u8 %4, %17 offset:%22\n\tds_read_u8_d16_hi %12, %17 offset:%30\n\t"
-        "ds_read_u8 %5, %17 offset:%23\n\tds_read_u8_d16_hi %13, %17 offset:%31\n\t"
-        "ds_read_u8 %6, %17 offset:%24\n\tds_read_u8_d16_hi %14, %17 offset:%32\n\t"
-        "ds_read_u8 %7, %17 offset:%25\n\tds_read_u8_d16_hi %15, %17 offset:%33\n\t"
+        "ds_read_u8 %0, %17 offset:%18\n\tds_read_u8 %8, %17 offset:%26\n\t"
+        "ds_read_u8 %1, %17 offset:%19\n\tds_read_u8 %9, %17 offset:%27\n\t"
+        "ds_read_u8 %2, %17 offset:%20\n\tds_read_u8 %10, %17 offset:%28\n\t"
+        "ds_read_u8 %3, %17 offset:%21\n\tds_read_u8 %11, %17 offset:%29\n\t"
+        "ds_read_u8 %4, %17 offset:%22\n\tds_read_u8 %12, %17 offset:%30\n\t"
+        "ds_read_u8 %5, %17 offset:%23\n\tds_read_u8 %13, %17 offset:%31\n\t"
+        "ds_read_u8 %6, %17 offset:%24\n\tds_read_u8 %14, %17 offset:%32\n\t"
+        "ds_read_u8 %7, %17 offset:%25\n\tds_read_u8 %15, %17 offset:%33\n\t"
         "ds_read_u8 %16, %17 offset:%34\n\t"
         "s_waitcnt lgkmcnt(0)"
         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]),
@@ -103,7 +103,7 @@ __device__ __forceinline__ int corner_strength(uint32_t at) {
           "i"(c0)
         : "memory");
 #pragma unroll
-    for (int j = 0; j < 8; j++) w[j] |= h[j];
+    for (int j = 0; j < 8; j++) w[j] |= h[j] << 16;          // one v_lshl_or_b32 per pair
     uint32_t lo[8], hi[8];
     arc_runs<true>(w, lo);        // smallest value of every run
     arc_runs<false>(w, hi);       // largest value of every run
