@@ -522,13 +522,24 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
 
     // ---- row pass: T[r][j] = sum_c K[c] * R[r][j-3+c]; a lane makes rows 2j, 2j+1 of four columns ----
     const RowTaps kt = make_row_taps(blurTaps);
+    // all three items' pixels are requested before the first is used: one LDS round trip for the pass, not three
+    uint32_t rowIn[kHIters][2][3];
 #pragma unroll
     for (int q = 0; q < kHIters; q++) {
         const uint32_t* p = reinterpret_cast<const uint32_t*>(R + (hItem[q] & 0xFFFFu));
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            rowIn[q][h][0] = p[12 * h];
+            rowIn[q][h][1] = p[12 * h + 1];
+            rowIn[q][h][2] = p[12 * h + 2];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kHIters; q++) {
         uint4 o[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const uint32_t A = p[12 * h], B = p[12 * h + 1], C = p[12 * h + 2];   // columns 4g-4 .. 4g+7
+            const uint32_t A = rowIn[q][h][0], B = rowIn[q][h][1], C = rowIn[q][h][2];   // columns 4g-4 .. 4g+7
             o[h].x = dot4(A, kt.a0, dot4(B, kt.b0, 0u));
             o[h].y = dot4(A, kt.a1, dot4(B, kt.b1, dot4(C, kt.c1, 0u)));
             o[h].z = dot4(A, kt.a2, dot4(B, kt.b2, dot4(C, kt.c2, 0u)));
@@ -554,13 +565,21 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
         const uint32_t we[4] = {k0 | (k1 << 16), k2 | (k3 << 16), k2 | (k1 << 16), k0};
         const uint32_t wo[4] = {k0 << 16, k1 | (k2 << 16), k3 | (k2 << 16), k1 | (k0 << 16)};
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        // an item's four row pairs are requested while the item before it is computed
+        uint4 tin[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) tin[0][r] = *reinterpret_cast<const uint4*>(Tb + (vItem[0] & 0xFFFFu) + r * 16);
 #pragma unroll
         for (int q = 0; q < kVIters; q++) {
-            const uint8_t* tp = Tb + (vItem[q] & 0xFFFFu);
+            if (q + 1 < kVIters) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    tin[(q + 1) & 1][r] = *reinterpret_cast<const uint4*>(Tb + (vItem[q + 1] & 0xFFFFu) + r * 16);
+            }
             uint4 e = make_uint4(32768u << 8, 32768u << 8, 32768u << 8, 32768u << 8), o = e;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint4 t = *reinterpret_cast<const uint4*>(tp + r * 16);
+                const uint4 t = tin[q & 1][r];
                 const us2 a = __builtin_bit_cast(us2, we[r]), b = __builtin_bit_cast(us2, wo[r]);
                 e.x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.x), a, e.x, true);
                 e.y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, t.y), a, e.y, true);
