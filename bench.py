@@ -64,6 +64,7 @@ PCIE_PEAK_GBS = 63.0           # PCIe Gen5 x16 (spec)
 # FP4 matrix peak (dense): 1024 SIMDs x one 32x32x64 instruction (65,536 multiply-adds) per 32 cycles x 2.4 GHz
 MFMA_FP4_PEAK_TFLOPS = 1024 * 2 * 65536 / 32 * 2.4e9 / 1e12
 LEGS = ("hd1080", "stereo", "hamming", "host_fed")
+LEG_SECONDS = 0.5              # shortest timed region of the hd1080 / stereo / host_fed legs (whole rounds of 48 launches)
 
 
 def parse():
@@ -365,7 +366,9 @@ class HostFedLeg:
 class StereoLeg:
     """configs[2]: left + right extraction (nFeatures 1200) and Frame::ComputeStereoMatches, pair p on rank p mod G."""
 
-    def __init__(self, R, B=128, sets=2):
+    # 256 pairs per launch and three sets in flight, like the headline's 256 frames and three contexts: 151.8 k pairs/s
+    # where 128 pairs x 2 sets give 140.8 k, 128 x 3 146.8 k, 256 x 2 147.8 k, 192 x 3 150.9 k, 64 x 3 127.1 k
+    def __init__(self, R, B=256, sets=3):
         import torch
         import my_orb_slam2_amd as m
         self.B = B
@@ -382,16 +385,22 @@ class StereoLeg:
                 return (torch.empty((B, cap, 7), dtype=torch.float32, device="cuda"),
                         torch.empty((B, cap, 32), dtype=torch.uint8, device="cuda"),
                         torch.zeros(B, dtype=torch.int32, device="cuda"))
-            self.sets.append(dict(exl=exl, exr=exr, L=alloc(), R=alloc(), hm=m.HammingMatcher(R.local),
+            hm = m.HammingMatcher(R.local)
+            # the three streams of a set, named explicitly (see ExtractLeg): inputs and outputs are resident and the
+            # timed region starts and ends with a device synchronisation
+            self.sets.append(dict(exl=exl, exr=exr, L=alloc(), R=alloc(), hm=hm,
+                                  sl=exl._torch_stream().cuda_stream, sr=exr._torch_stream().cuda_stream,
+                                  sm=hm._own_stream().cuda_stream,
                                   ur=torch.empty((B, cap), dtype=torch.float32, device="cuda"),
                                   z=torch.empty((B, cap), dtype=torch.float32, device="cuda")))
 
     def step(self, i):
         s = self.sets[i % len(self.sets)]
-        s["exl"].extract_batch_device(self.left, *s["L"])
-        s["exr"].extract_batch_device(self.right, *s["R"])
+        s["exl"].extract_batch_device(self.left, *s["L"], stream=s["sl"])
+        s["exr"].extract_batch_device(self.right, *s["R"], stream=s["sr"])
         # no host synchronisation: the call orders the three streams on the device (events)
-        s["hm"].compute_stereo_matches_device(s["exl"], s["exr"], *s["L"], *s["R"], self.bf, self.b, s["ur"], s["z"])
+        s["hm"].compute_stereo_matches_device(s["exl"], s["exr"], *s["L"], *s["R"], self.bf, self.b, s["ur"], s["z"],
+                                              stream=s["sm"])
 
     def finish(self):
         for s in self.sets:
@@ -543,7 +552,8 @@ def run_rank(a):
     # 32 frames of 1920x1080 per launch: about as many pixels as 256 frames of 752x480 need to fill the chip; 64 frames
     # per launch measured 6 % lower, 16 frames 14 % lower
     hd = ExtractLeg(R, 1920, 1080, 2000, 32, 64, nctx) if "hd1080" in legs else None
-    stereo = StereoLeg(R) if "stereo" in legs else None
+    # (the stereo leg's nine streams come up when its turn comes, after the 1080p leg's contexts are gone: with them
+    # alive beside it the 1080p leg ran 6 % slower, 76.4 k instead of 81.3 k frames/s)
     R.init_group()
     ranks_in_group = dist.get_world_size() if R.use_dist else 1
 
@@ -571,7 +581,8 @@ def run_rank(a):
         for i in range(hf.slots):
             hf.submit(i)
         fsteps = 48
-        fdt = R.timed(hf.submit, fsteps, 3)
+        fdt, frounds = R.timed(hf.submit, fsteps, 3, LEG_SECONDS)
+        fsteps *= frounds
         frames_s = R.world * hf.B * fsteps / fdt
         extra["host_fed"] = {"workload": "configs[1] with frames starting and results ending in pinned host memory: %d slots, "
                                          "each copy in -> orbx_extract_batch_device -> copy out on its own stream" % hf.slots,
@@ -586,7 +597,8 @@ def run_rank(a):
         del hf
     if hd is not None:
         hsteps = 48
-        hdt = R.timed(hd.launch, hsteps, 6)
+        hdt, hrounds = R.timed(hd.launch, hsteps, 6, LEG_SECONDS)
+        hsteps *= hrounds
         hd_fps = R.world * hd.B * hsteps / hdt
         hd_stage = hd.stage_ms(5)
         extra["hd1080"] = {"workload": "configs[3]: synthetic 1920x1080 frames, nFeatures 2000, 8 levels, frame-parallel",
@@ -597,9 +609,13 @@ def run_rank(a):
                            "roofline": dict(hbm_roofline(hd_stage, STAGE_BYTES_HD, hd.B),
                                             path_bytes_per_frame=BYTES_PER_FRAME_HD,
                                             path_frac=round(BYTES_PER_FRAME_HD * hd_fps / R.world / 1e9 / HBM_PEAK_GBS, 5))}
+    del hd
+    torch.cuda.empty_cache()
+    stereo = StereoLeg(R) if "stereo" in legs else None
     if stereo is not None:
         ssteps = 48
-        sdt = R.timed(stereo.step, ssteps, 6)
+        sdt, srounds = R.timed(stereo.step, ssteps, 6, LEG_SECONDS)
+        ssteps *= srounds
         stereo.finish()
         matched = float((stereo.sets[0]["ur"] >= 0).sum().item()) / stereo.B
         st_stage = stereo.stage_ms()
@@ -614,7 +630,7 @@ def run_rank(a):
                                             note="stage times of ONE side's extraction (the other side repeats them) and of "
                                                  "the ComputeStereoMatches kernels, each alone")}
     host64 = main.host[:64]
-    del main, hd, stereo
+    del main, stereo
     torch.cuda.empty_cache()
     if "hamming" in legs:
         extra["hamming"] = hamming_leg(R, a)
