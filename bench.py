@@ -202,6 +202,7 @@ class Rank:
         self.local = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
         # ORBX_BENCH_FORCE_DIST=1 runs the collective code path with a single rank (rehearsal on a one-GPU box)
         self.use_dist = self.world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"
+        self.backend_note = None
 
     def init_group(self):
         import torch
@@ -210,10 +211,31 @@ class Rank:
             return
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        kw = {}
         if self.a.backend == "nccl":
-            kw["device_id"] = torch.device("cuda", self.local)
-        dist.init_process_group(self.a.backend, rank=self.rank, world_size=self.world, **kw)
+            # RCCL over xGMI is the backend of record. If its communicator does not come up on this node (every rank
+            # sees that at the same point: the first collective below), the ranks meet again over gloo on the next
+            # port and the result line says so; extraction and stereo use no collective in their data path, and the
+            # kNN all-gather of 16 bytes per query then travels through host memory.
+            try:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local))
+                t = torch.ones(1, device=torch.device("cuda", self.local))
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+                if int(t.item()) != self.world:
+                    raise RuntimeError("all_reduce over RCCL returned %r for %d ranks" % (t.item(), self.world))
+                return
+            except Exception as e:                          # noqa: BLE001 (any failure of the backend takes this path)
+                self.backend_note = "nccl failed (%s: %s); gloo used instead" % (type(e).__name__, str(e)[:200])
+                print("bench.py: rank %d: %s" % (self.rank, self.backend_note), file=sys.stderr)
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:                           # noqa: BLE001
+                    pass
+                self.a.backend = "gloo"
+                os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
+        dist.init_process_group(self.a.backend, rank=self.rank, world_size=self.world)
 
     def fence(self):
         import torch
@@ -666,7 +688,8 @@ def run_rank(a):
                    "distinct_frames_per_gpu": a.unique,
                    "mean_keypoints_per_frame": round(kp_mean, 1), "inputs": "resident in HBM",
                    "contexts_per_gpu": nctx, "blur_taps": "CV_4_0_0", "quadtree_tie_break": "creation order",
-                   "ranks_in_group": ranks_in_group, "backend": a.backend if R.use_dist else "none"},
+                   "ranks_in_group": ranks_in_group, "backend": a.backend if R.use_dist else "none",
+                   **({"backend_note": R.backend_note} if R.backend_note else {})},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "traffic_source": pmc_source if traffic is not None else None,
