@@ -525,3 +525,19 @@ def test_cpp_api_walk_program():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=100)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "api walk ok" in out.stdout
+
+
+def test_cpp_latency_program():
+    """tools/latency_single.cpp times the drop-in call from plain C++ (one 752x480 frame in host memory per call, as
+    src/Frame.cc:285-291 calls the extractor). The test checks that it runs and finds the frames' keypoints; the
+    time it prints is recorded, not judged (a loose bound catches a path that has fallen off the replayed graph)."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "latency_single")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe, "300"], capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    print(r)
+    assert r["mean_keypoints"] > 900 and 0 < r["median_us"] < 1000
