@@ -574,11 +574,21 @@ extern "C" int orbx_extract_batch(orbx_ctx* c, const uint8_t* images, int nframe
                 if (e0 == hipSuccess) {
                     c->capturing = true;
                     e1 = hipMemcpyAsync(c->stageImg, c->pinIn, fstride * (size_t)nframes, hipMemcpyHostToDevice, c->stream);
+                    // The last kernel writes counts, keypoints and descriptors straight into the pinned host block
+                    // (its records leave as wide stores): no copy back, one node less in the chain.
+                    uint8_t* outBlock = c->stageOut;
+                    void* mapped = nullptr;
+                    const char* zc = getenv("ORBX_ZEROCOPY_OUT");
+                    const bool direct = !(zc && zc[0] == '0') &&
+                                        hipHostGetDevicePointer(&mapped, c->pinOut, 0) == hipSuccess && mapped;
+                    (void)hipGetLastError();
+                    if (direct) outBlock = static_cast<uint8_t*>(mapped);
                     r1 = orbx_extract_batch_device(c, c->stageImg, nframes, width, height, pitch, fstride,
-                                                   reinterpret_cast<orbx_keypoint*>(c->stageOut + lay.kps),
-                                                   c->stageOut + lay.desc, cap, reinterpret_cast<int32_t*>(c->stageOut),
+                                                   reinterpret_cast<orbx_keypoint*>(outBlock + lay.kps),
+                                                   outBlock + lay.desc, cap, reinterpret_cast<int32_t*>(outBlock),
                                                    c->stream);
-                    e2 = hipMemcpyAsync(c->pinOut, c->stageOut, lay.total, hipMemcpyDeviceToHost, c->stream);
+                    if (!direct)
+                        e2 = hipMemcpyAsync(c->pinOut, c->stageOut, lay.total, hipMemcpyDeviceToHost, c->stream);
                     c->capturing = false;
                     e3 = hipStreamEndCapture(c->stream, &graph);
                 }

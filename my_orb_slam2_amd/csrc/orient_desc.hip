@@ -630,7 +630,31 @@ __global__ __launch_bounds__(64 * WAVES) void orient_desc_kernel(FrameSet fs, Py
         const int t0 = Bl[(int)(i0 - kMagicBias)];
         const int t1 = Bl[(int)(i1 - kMagicBias)];
         const unsigned long long bits = __builtin_amdgcn_ballot_w64(t0 < t1);
-        if (lane == 0) desc64[round] = bits;   // pair 64*round + j is bit j%8 of byte 8*round + j/8
+        if (OWN_PREFIX) {
+            // calls of a few frames may write straight into the caller's (pinned host) memory: the record leaves as
+            // two wide stores made by neighbouring lanes instead of eleven small ones from lane 0
+            // (staged in the row-sum table, which nobody reads any more; R holds the blurred patch being sampled)
+            if (lane == 0) reinterpret_cast<unsigned long long*>(Tb)[round] = bits;
+        } else if (lane == 0) {
+            desc64[round] = bits;   // pair 64*round + j is bit j%8 of byte 8*round + j/8
+        }
+    }
+    if (OWN_PREFIX) {
+        if (lane == 0) {
+            float* kf = reinterpret_cast<float*>(Tb + 32);
+            kf[0] = l ? __fmul_rn((float)kx, __uint_as_float(rec[4])) : (float)kx;
+            kf[1] = l ? __fmul_rn((float)ky, __uint_as_float(rec[4])) : (float)ky;
+            kf[2] = __uint_as_float(rec[5]);
+            kf[3] = angle;
+            kf[4] = (float)cand_score(packed);
+            reinterpret_cast<int32_t*>(kf)[5] = l;
+            reinterpret_cast<int32_t*>(kf)[6] = -1;
+        }
+        wave_sync();
+        const uint32_t word = reinterpret_cast<const uint32_t*>(Tb)[lane & 15];
+        if (lane < 8) reinterpret_cast<uint32_t*>(desc64)[lane] = word;
+        else if (lane < 15) reinterpret_cast<uint32_t*>(kpsOut + ((long long)f * cap + outIdx))[lane - 8] = word;
+        return;
     }
     if (lane == 0) {
         orbx_keypoint kp;
