@@ -281,10 +281,18 @@ __global__ __launch_bounds__(256, WPS) void knn2_fp4_kernel(const uint32_t* __re
     const int64_t j0 = (int64_t)blockIdx.y * chunkRows;
     const int rows = (int)min(chunkRows, ndb - j0);
     const int nrb = (rows + 31) >> 5;
+    // DIAG == 3: `db` holds the rows already expanded to FP4 (128 bytes per row, dword d of a row as 16 bytes at
+    // d * 16): no table look-ups in the loop, four times the bytes
+    constexpr bool PREX = DIAG == 3;
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(db + j0 * 8), 0, rows * 32, 0x00027000);
-    const int laneOff = j * 32 + 16 * h;
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(db + j0 * (PREX ? 32 : 8)), 0, rows * (PREX ? 128 : 32), 0x00027000);
+    const int laneOff = PREX ? j * 128 + 64 * h : j * 32 + 16 * h;
     u4 raw = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff, 0, 0));
+    u4 rawx[3];
+    if (PREX) {
+#pragma unroll
+        for (int m = 1; m < 4; m++) rawx[m - 1] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff + 16 * m, 0, 0));
+    }
 
     auto tile = [&](const uint32_t (&A)[4][4], int b) {
         v16f acc = {0};
@@ -334,11 +342,26 @@ __global__ __launch_bounds__(256, WPS) void knn2_fp4_kernel(const uint32_t* __re
 
     for (int rb = 0; rb < nrb; rb++) {
         uint32_t A[4][4];
+        if (PREX) {
 #pragma unroll
-        for (int m = 0; m < 4; m++)
+            for (int k = 0; k < 4; k++) A[0][k] = raw[k];
 #pragma unroll
-            for (int k = 0; k < 4; k++) A[m][k] = lut[(raw[m] >> (8 * k)) & 255u];
-        if (rb + 1 < nrb) raw = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff, (rb + 1) * 1024, 0));
+            for (int m = 1; m < 4; m++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) A[m][k] = rawx[m - 1][k];
+            if (rb + 1 < nrb) {
+                raw = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff, (rb + 1) * 4096, 0));
+#pragma unroll
+                for (int m = 1; m < 4; m++)
+                    rawx[m - 1] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff + 16 * m, (rb + 1) * 4096, 0));
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) A[m][k] = lut[(raw[m] >> (8 * k)) & 255u];
+            if (rb + 1 < nrb) raw = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, laneOff, (rb + 1) * 1024, 0));
+        }
         const int rowBase = rb * 32 + 4 * h;
         if (PAIR && DIAG == 2) {
             // both tiles' matrix instructions, both min trees, ONE branch for the pair
@@ -543,6 +566,21 @@ __global__ void fold_kernel(const Partial* partial, int nchunks, int64_t nq, int
     idx[qi] = bi; d1[qi] = b1; d2[qi] = b2;
 }
 
+// dword d of row r -> sixteen bytes: its four bytes through the nibble table (bit -> 0b0010)
+__global__ void expand_rows_kernel(const uint32_t* __restrict__ db, int64_t ndw, uint32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ndw) return;
+    const uint32_t v = db[i];
+    uint32_t o[4];
+    for (int k = 0; k < 4; k++) {
+        const uint32_t byte = (v >> (8 * k)) & 255u;
+        uint32_t e = 0;
+        for (int b = 0; b < 8; b++) e |= ((byte >> b) & 1u) << (4 * b + 1);
+        o[k] = e;
+    }
+    reinterpret_cast<uint4*>(out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 static uint64_t sm64(uint64_t& s) {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -587,12 +625,24 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dd2, nq * 4));
     CK(hipMemcpy(dq, hq.data(), nq * 32, hipMemcpyHostToDevice));
     CK(hipMemcpy(ddb, hdb.data(), ndb * 32, hipMemcpyHostToDevice));
+    uint32_t* ddbx = nullptr;
+    if (mode == 17 || mode == 18) {
+        CK(hipMalloc(&ddbx, std::max<int64_t>(ndb * 128, 128)));
+        hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((ndb * 8 + 255) / 256)), dim3(256), 0, 0, ddb, ndb * 8, ddbx);
+        CK(hipDeviceSynchronize());
+    }
     auto run = [&]() {
         auto go = [&](auto kernel, int nqb) {
             dim3 grid((unsigned)((nq + 4 * 32 * nqb - 1) / (4 * 32 * nqb)), nchunks);
             hipLaunchKernelGGL(kernel, grid, dim3(256), 0, 0, dq, nq, ddb, ndb, chunkRows, 0, part);
         };
-        if (mode == 2) go(knn2_fp4_kernel<8, false, 2>, 8);
+        if (mode == 17 || mode == 18) {
+            const int nqb = 8;
+            dim3 grid((unsigned)((nq + 4 * 32 * nqb - 1) / (4 * 32 * nqb)), nchunks);
+            if (mode == 17) hipLaunchKernelGGL((knn2_fp4_kernel<8, false, 2, true, 3>), grid, dim3(256), 0, 0, dq, nq, ddbx, ndb, chunkRows, 0, part);
+            else hipLaunchKernelGGL((knn2_fp4_kernel<8, true, 2, true, 3>), grid, dim3(256), 0, 0, dq, nq, ddbx, ndb, chunkRows, 0, part);
+        }
+        else if (mode == 2) go(knn2_fp4_kernel<8, false, 2>, 8);
         else if (mode == 3) go(knn2_fp4_kernel<6, true, 2>, 6);
         else if (mode == 4) go(knn2_fp4_kernel<2, true, 2>, 2);
         else if (mode == 5) go(knn2_fp4_kernel<1, false, 2>, 1);
@@ -653,7 +703,7 @@ int main(int argc, char** argv) {
         }
     }
     printf("{\"mode\": \"%s\", \"expand\": %d, \"nq\": %lld, \"ndb\": %lld, \"chunk_rows\": %lld, \"ms\": %.3f, \"pairs_per_s\": %.4g, \"checked\": %s, \"wrong\": %lld}\n",
-           mode == 0 ? "i8" : mode == 1 ? "fp4" : mode == 2 ? "fp4_v2_8" : mode == 3 ? "fp4_v2_6pair" : mode == 4 ? "fp4_v2_2pair" : mode == 5 ? "fp4_v2_1" : mode == 6 ? "fp4_v2_16pair_1wave" : mode == 7 ? "fp4_v2_4pair" : mode == 8 ? "fp4_v2_8pair" : mode == 9 ? "fp4_v3_8" : mode == 10 ? "fp4_v3_2" : mode == 11 ? "fp4_v3_4" : mode == 12 ? "fp4_v2_8_unscaled" : mode == 13 ? "fp4_v2_2_unscaled" : mode == 14 ? "fp4_v2_8_no_update_path" : mode == 15 ? "fp4_v2_6_joint_pair" : "fp4_v2_4_joint_pair", expand, (long long)nq, (long long)ndb, (long long)chunkRows, ms, (double)nq * ndb / (ms * 1e-3),
+           mode == 0 ? "i8" : mode == 1 ? "fp4" : mode == 2 ? "fp4_v2_8" : mode == 3 ? "fp4_v2_6pair" : mode == 4 ? "fp4_v2_2pair" : mode == 5 ? "fp4_v2_1" : mode == 6 ? "fp4_v2_16pair_1wave" : mode == 7 ? "fp4_v2_4pair" : mode == 8 ? "fp4_v2_8pair" : mode == 9 ? "fp4_v3_8" : mode == 10 ? "fp4_v3_2" : mode == 11 ? "fp4_v3_4" : mode == 12 ? "fp4_v2_8_unscaled" : mode == 13 ? "fp4_v2_2_unscaled" : mode == 14 ? "fp4_v2_8_no_update_path" : mode == 15 ? "fp4_v2_6_joint_pair" : mode == 17 ? "fp4_v2_8_rows_kept_expanded" : mode == 18 ? "fp4_v2_8pair_rows_kept_expanded" : "fp4_v2_4_joint_pair", expand, (long long)nq, (long long)ndb, (long long)chunkRows, ms, (double)nq * ndb / (ms * 1e-3),
            check ? "true" : "false", bad);
     return bad ? 3 : 0;
 }
