@@ -327,19 +327,22 @@ __global__ __launch_bounds__(64 * kCellsPerBlock) void fast_cells_kernel(FrameSe
 #pragma unroll
                 for (int j = 0; j < 4; j++) m[j] &= ym;
             }
-            // row-major rank: everything queued by lower lanes, then this lane's own earlier pixels (what earlier
-            // steps queued is a scalar and goes into the base address)
-            int pos = 0;
+            // A quarter of all steps let no pixel through (flat parts of the image): nothing to rank or store then.
+            if ((m[0] | m[1] | m[2] | m[3]) != 0) {                // wave-uniform
+                // row-major rank: everything queued by lower lanes, then this lane's own earlier pixels (what earlier
+                // steps queued is a scalar and goes into the base address)
+                int pos = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[j], pos));
-            uint16_t* qdst = queue + nq;
+                for (int j = 0; j < 4; j++)
+                    pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[j], pos));
+                uint16_t* qdst = queue + nq;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const bool pass = __builtin_amdgcn_inverse_ballot_w64(m[j]);
-                if (pass) qdst[pos] = (uint16_t)(e0 + j);
-                if (j < 3) pos = add_mask_bit(pos, m[j]);          // pos += pass
-                nq += __popcll(m[j]);
+                for (int j = 0; j < 4; j++) {
+                    const bool pass = __builtin_amdgcn_inverse_ballot_w64(m[j]);
+                    if (pass) qdst[pos] = (uint16_t)(e0 + j);
+                    if (j < 3) pos = add_mask_bit(pos, m[j]);          // pos += pass
+                    nq += __popcll(m[j]);
+                }
             }
             e0 += rowsPerIter * PITCH;
             t32 += rowsPerIter * P4;
